@@ -1,0 +1,100 @@
+"""CPU-side tests: config plumbing, C-ABI exports (no compute without a GPU), host-side helpers."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, load_golden_config
+from rl_brain_trainer_amd import config as kcfg
+from rl_brain_trainer_amd import native
+
+
+def test_library_exports_every_declared_symbol():
+    L = native.load()
+    missing = [s for s in native.declared_symbols() if not hasattr(L, s)]
+    assert not missing, missing
+    assert L.kp1_config_size() == C.sizeof(kcfg.Kp1Config)
+
+
+def test_library_default_config_matches_binding():
+    L = native.load()
+    c = kcfg.Kp1Config()
+    assert L.kp1_config_default(C.byref(c)) == 0
+    assert bytes(c) == bytes(kcfg.default_config())
+
+
+def test_seed_state_matches_numpy():
+    L = native.load()
+    for seed in (0, 7, 806, 931, 2**32 + 5, 2**63 + 1):
+        st = kcfg.RngState()
+        assert L.kp1_rng_seed_state(seed, C.byref(st)) == 0
+        ref = np.random.default_rng(seed).bit_generator.state["state"]
+        assert (st.state_hi << 64 | st.state_lo) == ref["state"]
+        assert (st.inc_hi << 64 | st.inc_lo) == ref["inc"]
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = native.load()
+    h = C.c_void_p()
+    rc = L.kp1_create(C.byref(kcfg.default_config()), 4, 0, 0, 0, 0, None, C.byref(h))
+    assert rc == -2 and b"no HIP device" in L.kp1_last_error()
+    from rl_brain_trainer_amd.vec_env import ArmKinematicVecEnv
+
+    with pytest.raises(native.Kp1Error):
+        ArmKinematicVecEnv(kcfg.EnvConfig(c=kcfg.default_config()), 4)
+
+
+def test_unknown_reward_key_raises_like_reference_dataclass():
+    cfg = json.loads((GOLDEN / "configs" / "approach_default.json").read_text())
+    cfg["env"]["reward"]["not_a_field"] = 1.0
+    with pytest.raises(TypeError):
+        kcfg.to_env_config(cfg)
+    cfg = json.loads((GOLDEN / "configs" / "approach_default.json").read_text())
+    cfg["env"]["mode"] = "bridge"
+    with pytest.raises(ValueError):
+        kcfg.to_env_config(cfg)
+
+
+def test_dwell_steps_target_quirk():
+    # policy_config.py:146: dwell_steps_target comes from termination.success_dwell_steps
+    cfg = load_golden_config("dock_workspace_handoff_noop_ft_12env_raw")
+    assert cfg.c.env.dwell_steps_target == 5 and cfg.c.termination.success_dwell_steps == 5
+    assert len(cfg.handoff_states) > 0 and cfg.c.dock_reset.handoff_state_probability == 0.95
+
+
+BUILTIN = {
+    "approach_default": ("workspace", None),
+    "workspace_expansion_bigtrain": ("workspace", "workspace_expansion_bigtrain.yaml"),
+    "workspace_expansion_1h_extend": ("workspace", "workspace_expansion_1h_extend.yaml"),
+    "workspace_full_coverage_randomstart_overnight": ("workspace", "workspace_full_coverage_randomstart_overnight.yaml"),
+    "dock_default": ("dock", None),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BUILTIN))
+def test_builtin_yaml_resolves_to_reference_config(name):
+    """Our own YAML files + loaders must resolve to the same env struct as the reference's resolved config."""
+    kind, fname = BUILTIN[name]
+    path = kcfg.builtin_config_dir() / fname if fname else None
+    cfg = kcfg.load_workspace_expansion_config(path) if kind == "workspace" else kcfg.load_dock_config(path)
+    ours = kcfg.to_env_config(cfg, handoff_base_dirs=(GOLDEN,))
+    gold = load_golden_config(name)
+    assert bytes(ours.c) == bytes(gold.c)
+    assert ours.stage_names == gold.stage_names
+    gold_cfg = json.loads((GOLDEN / "configs" / f"{name}.json").read_text())
+    assert kcfg.to_algorithm_kwargs(cfg) == kcfg.to_algorithm_kwargs(gold_cfg)
+
+
+def test_finisher_yaml_resolves_to_reference_config():
+    raw = kcfg.load_yaml_file(kcfg.builtin_config_dir() / "dock_workspace_handoff_noop_ft_12env.yaml")
+    raw["env"]["dock_reset"]["handoff_state_buffer_path"] = "handoff_state_buffer.json"
+    ours = kcfg.to_env_config(raw, handoff_base_dirs=(GOLDEN,))
+    gold = load_golden_config("dock_workspace_handoff_noop_ft_12env_raw")
+    assert bytes(ours.c) == bytes(gold.c)

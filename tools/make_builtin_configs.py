@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Emit rl_brain_trainer_amd/configs/*.yaml from the resolved-config fixtures in tests/golden/configs/.
+
+The hyper-parameter VALUES are the reference's (they are facts the engine must reproduce); the files are
+written by this tool as minimal overlays on our own defaults, in our own layout (flow-style vectors).
+tests/test_host_logic.py checks that each file resolves to the same kp1_config bytes as the fixture.
+"""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+
+import yaml
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLD = ROOT / "tests" / "golden" / "configs"
+OUT = ROOT / "rl_brain_trainer_amd" / "configs"
+
+
+class Flow(list):
+    pass
+
+
+def _flow_rep(dumper, data):
+    return dumper.represent_sequence("tag:yaml.org,2002:seq", data, flow_style=True)
+
+
+yaml.add_representer(Flow, _flow_rep, Dumper=yaml.SafeDumper)
+
+
+def flowify(x):
+    if isinstance(x, dict):
+        return {k: flowify(v) for k, v in x.items()}
+    if isinstance(x, list):
+        if all(not isinstance(v, (dict, list)) for v in x):
+            return Flow(x)
+        return [flowify(v) for v in x]
+    return x
+
+
+def diff(merged: dict, base: dict) -> dict:
+    out = {}
+    for k, v in merged.items():
+        if k not in base:
+            out[k] = v
+        elif isinstance(v, dict) and isinstance(base[k], dict):
+            d = diff(v, base[k])
+            if d:
+                out[k] = d
+        elif v != base[k]:
+            out[k] = v
+    return out
+
+
+def load(name: str) -> dict:
+    return json.loads((GOLD / f"{name}.json").read_text())
+
+
+def emit(fname: str, body: dict, header: str, base_config: str | None = None) -> None:
+    text = "# " + header.replace("\n", "\n# ") + "\n"
+    if base_config:
+        text += f"base_config: {base_config}\n"
+    text += yaml.dump(flowify(body), Dumper=yaml.SafeDumper, sort_keys=False, width=160, default_flow_style=False)
+    (OUT / fname).write_text(text)
+
+
+def main() -> None:
+    OUT.mkdir(exist_ok=True)
+    approach = load("approach_default")
+    ppo = {"algorithms": approach["algorithms"]}
+    approach_only = {k: v for k, v in approach.items() if k != "algorithms"}
+    approach_only["algorithms"] = {"ppo": {}}
+    emit("approach_default.yaml", approach_only,
+         "Approach-mode defaults (Stage 0-5 shells, 20-step episodes).\nValues: reference kinematic_phase1/configs/approach_default.yaml.")
+    emit("ppo_default.yaml", ppo, "PPO defaults.  Values: reference kinematic_phase1/configs/ppo_default.yaml.")
+    dock = load("dock_default")
+    dock_only = {k: v for k, v in dock.items() if k != "algorithms"}
+    dock_only["algorithms"] = {"ppo": {}}
+    emit("dock_default.yaml", dock_only, "Dock (Finisher) mode defaults.  Values: reference kinematic_phase1/configs/dock_default.yaml.")
+
+    base = approach  # approach_default <- ppo_default
+    big = load("workspace_expansion_bigtrain")
+    emit("workspace_expansion_bigtrain.yaml", diff(big, base),
+         "Stage 0-9 workspace-expansion run (BASELINE config 2 pins stage 5): overlay on approach_default <- ppo_default.\n"
+         "Values: reference kinematic_phase1/configs/workspace_expansion_bigtrain.yaml.")
+    ext = load("workspace_expansion_1h_extend")
+    emit("workspace_expansion_1h_extend.yaml", diff(ext, base),
+         "Stage 0-11 table incl. the stage 10/11 stress shells (BASELINE config 3 pins stage 11).\n"
+         "Values: reference kinematic_phase1/configs/workspace_expansion_1h_extend.yaml.")
+    rnd = load("workspace_full_coverage_randomstart_overnight")
+    emit("workspace_full_coverage_randomstart_overnight.yaml", diff(rnd, ext),
+         "Random-start mixed-workspace run (BASELINE config 4): overlay on workspace_expansion_1h_extend.yaml.\n"
+         "Values: reference kinematic_phase1/configs/workspace_full_coverage_randomstart_overnight.yaml.",
+         base_config="workspace_expansion_1h_extend.yaml")
+    fin = load("dock_workspace_handoff_noop_ft_12env_raw")
+    fin["env"]["dock_reset"]["handoff_state_buffer_path"] = ""
+    emit("dock_workspace_handoff_noop_ft_12env.yaml", fin,
+         "Finisher (dock mode, 36 steps, handoff-state resets).  The evaluator loads this file raw (no default merge).\n"
+         "handoff_state_buffer_path is left empty: point it at a buffer produced by the handoff-buffer builder.\n"
+         "Values: reference kinematic_phase1/configs/dock_workspace_handoff_noop_ft_12env.yaml.")
+    print("wrote", sorted(p.name for p in OUT.glob("*.yaml")))
+
+
+if __name__ == "__main__":
+    main()
