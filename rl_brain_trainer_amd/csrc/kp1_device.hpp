@@ -36,6 +36,8 @@ __device__ __forceinline__ float kp_pow(float a, float b) { return powf(a, b); }
 __device__ __forceinline__ double kp_pow(double a, double b) { return pow(a, b); }
 __device__ __forceinline__ bool kp_isfinite(float a) { return isfinite(a); }
 __device__ __forceinline__ bool kp_isfinite(double a) { return isfinite(a); }
+__device__ __forceinline__ float kp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double kp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <typename R> __device__ __forceinline__ R kp_max(R a, R b) { return a > b ? a : b; }
 template <typename R> __device__ __forceinline__ R kp_min(R a, R b) { return a < b ? a : b; }
 template <typename R> __device__ __forceinline__ R kp_clip(R x, R lo, R hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -112,28 +114,33 @@ struct EnvState {
 };
 
 // ---- forward kinematics (V51/ee_fk.py:98-134) ----------------------------------------------
+// Bit-reproducibility: contraction is off and every multiply-add is an explicit fma, so the same q gives the same
+// pose bits at every call site (reset, step, set_state).  A zero action therefore leaves the pose error exactly
+// unchanged, as in the reference, and cannot bump the drift counter through last-bit noise.
 template <typename R>
 __device__ __forceinline__ void fk_pose6(const DevFk<R>& __restrict__ k, const R* __restrict__ q, R* __restrict__ pose) {
+#pragma clang fp contract(off)
   R Rm[9], p[3];
   R s, c;
   // joint 0 (prismatic) + joint 1 origin: pure translation
 #pragma unroll
-  for (int i = 0; i < 3; ++i) p[i] = k.p01[i] + k.v0[i] * q[0];
+  for (int i = 0; i < 3; ++i) p[i] = kp_fma(k.v0[i], q[0], k.p01[i]);
   kp_sincos(q[1], &s, &c);
 #pragma unroll
-  for (int e = 0; e < 9; ++e) Rm[e] = k.k1[0][e] + c * k.kc[0][e] + s * k.ks[0][e];
+  for (int e = 0; e < 9; ++e) Rm[e] = kp_fma(s, k.ks[0][e], kp_fma(c, k.kc[0][e], k.k1[0][e]));
 #pragma unroll
   for (int j = 2; j < NJ; ++j) {
     const int m = j - 1;
     kp_sincos(q[j], &s, &c);
     R D[9], Rn[9];
 #pragma unroll
-    for (int e = 0; e < 9; ++e) D[e] = k.k1[m][e] + c * k.kc[m][e] + s * k.ks[m][e];
+    for (int e = 0; e < 9; ++e) D[e] = kp_fma(s, k.ks[m][e], kp_fma(c, k.kc[m][e], k.k1[m][e]));
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      p[r] += Rm[3 * r + 0] * k.p[j - 2][0] + Rm[3 * r + 1] * k.p[j - 2][1] + Rm[3 * r + 2] * k.p[j - 2][2];
+      p[r] = kp_fma(Rm[3 * r + 2], k.p[j - 2][2], kp_fma(Rm[3 * r + 1], k.p[j - 2][1], kp_fma(Rm[3 * r + 0], k.p[j - 2][0], p[r])));
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc) Rn[3 * r + cc] = Rm[3 * r + 0] * D[cc] + Rm[3 * r + 1] * D[3 + cc] + Rm[3 * r + 2] * D[6 + cc];
+      for (int cc = 0; cc < 3; ++cc)
+        Rn[3 * r + cc] = kp_fma(Rm[3 * r + 2], D[6 + cc], kp_fma(Rm[3 * r + 1], D[3 + cc], Rm[3 * r + 0] * D[cc]));
     }
 #pragma unroll
     for (int e = 0; e < 9; ++e) Rm[e] = Rn[e];
@@ -141,14 +148,15 @@ __device__ __forceinline__ void fk_pose6(const DevFk<R>& __restrict__ k, const R
   pose[0] = p[0];
   pose[1] = p[1];
   pose[2] = p[2];
-  pose[3] = kp_atan2(Rm[7], Rm[8]);                                     // roll  = atan2(R21, R22)
-  pose[4] = kp_atan2(-Rm[6], kp_sqrt(Rm[0] * Rm[0] + Rm[3] * Rm[3]));   // pitch = atan2(-R20, sqrt(R00^2 + R10^2))
-  pose[5] = kp_atan2(Rm[3], Rm[0]);                                     // yaw   = atan2(R10, R00)
+  pose[3] = kp_atan2(Rm[7], Rm[8]);                                              // roll  = atan2(R21, R22)
+  pose[4] = kp_atan2(-Rm[6], kp_sqrt(kp_fma(Rm[3], Rm[3], Rm[0] * Rm[0])));      // pitch = atan2(-R20, sqrt(R00^2 + R10^2))
+  pose[5] = kp_atan2(Rm[3], Rm[0]);                                              // yaw   = atan2(R10, R00)
 }
 
 // KP1/kinematics/pose_utils.py:11-12 wrap_to_pi, numpy floor-mod
 template <typename R>
 __device__ __forceinline__ R wrap_to_pi(R v) {
+#pragma clang fp contract(off)
   const R PI = (R)3.141592653589793;
   const R TWO_PI = (R)2.0 * PI;
   R m = kp_fmod(v + PI, TWO_PI);
@@ -158,13 +166,14 @@ __device__ __forceinline__ R wrap_to_pi(R v) {
 // KP1/kinematics/pose_utils.py:21-30: both error norms of curr vs goal
 template <typename R>
 __device__ __forceinline__ void pose_error_norms(const R* curr, const R* goal, R* pos_err, R* ori_err, R* pos_norm, R* ori_norm) {
+#pragma clang fp contract(off)
   R sp = 0, so = 0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     pos_err[i] = goal[i] - curr[i];
     ori_err[i] = wrap_to_pi<R>(goal[3 + i] - curr[3 + i]);
-    sp += pos_err[i] * pos_err[i];
-    so += ori_err[i] * ori_err[i];
+    sp = kp_fma(pos_err[i], pos_err[i], sp);  // explicit: same bits at every call site (prev vs curr comparison, :263)
+    so = kp_fma(ori_err[i], ori_err[i], so);
   }
   *pos_norm = kp_sqrt(sp);
   *ori_norm = kp_sqrt(so);
@@ -559,11 +568,19 @@ __device__ __forceinline__ int pcg_integers(Pcg& r, int low, int high_exclusive)
   }
   return low + (int)(m >> 32);
 }
+// Generator.uniform: low + (high - low) * u with the product rounded BEFORE the add (numpy does not fuse);
+// contraction is switched off here so the device compiler cannot turn it into an FMA (HIP's __dmul_rn/__dadd_rn are
+// plain operators and would still be contracted): samples stay bit-exact.
+__device__ __forceinline__ double uniform_scale(double lo, double range, double u) {
+#pragma clang fp contract(off)
+  double prod = range * u;
+  return lo + prod;
+}
 __device__ __forceinline__ void pcg_uniform_sym7(Pcg& r, const double* noise, double* out) {
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {
     double lo = -noise[i], range = noise[i] - lo;
-    out[i] = lo + range * pcg_double(r);
+    out[i] = uniform_scale(lo, range, pcg_double(r));
   }
 }
 __device__ __forceinline__ bool any_positive7(const double* v) {
@@ -590,7 +607,7 @@ __device__ __forceinline__ void sample_joint_configuration(const DevSampler& __r
     double span = s.upper[i] - s.lower[i];
     double margin = fmax(span * margin_fraction, 1e-6);
     double lo = s.lower[i] + margin, hi = s.upper[i] - margin;
-    out[i] = lo + (hi - lo) * pcg_double(r);
+    out[i] = uniform_scale(lo, hi - lo, pcg_double(r));
   }
 }
 // KP1/envs/reset_samplers.py:344-390
@@ -647,7 +664,7 @@ struct ResetSample {
 };
 
 // KP1/envs/reset_samplers.py:213-305
-__device__ __noinline__ void sample_random_start_pair(const DevSampler& __restrict__ s, Pcg& r, int stage_index, ResetSample& o) {
+__device__ __forceinline__ void sample_random_start_pair(const DevSampler& __restrict__ s, Pcg& r, int stage_index, ResetSample& o) {
   const kp1_random_start& c = s.rs;
   const int n = s.n_stages;
   int current = kp_clipi(stage_index, 0, n - 1);

@@ -58,7 +58,7 @@ __device__ __forceinline__ void store_obs_row(float* __restrict__ obs, int64_t i
 
 // Sampling half of reset(): fills a ResetSample in fp64.  KP1/envs/reset_samplers.py:168-210, 426-515.
 template <int MODE>
-__device__ __noinline__ void sample_reset(const DevSampler& __restrict__ s, const kp1_handoff_state* __restrict__ handoff, Pcg& rng,
+__device__ __forceinline__ void sample_reset(const DevSampler& __restrict__ s, const kp1_handoff_state* __restrict__ handoff, Pcg& rng,
                                           int stage_index, ResetSample& o, bool& has_dq_pa, bool& has_goal_pose) {
   has_dq_pa = false;
   has_goal_pose = false;

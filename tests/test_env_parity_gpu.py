@@ -88,8 +88,10 @@ def test_step_trace_gpu(name, real):
         ctx = f"{name}[{real}] step {t}"
         gold_done = (int(g["terminated"][t]) * 1) | (int(g["truncated"][t]) * 2) | (int(g["success"][t]) * 4)
         if not strict:
+            # ties: a gated quantity within 2e-6 of its threshold, or a "did the error grow" comparison (drift counter,
+            # :263) between two errors closer than the fp32 pose noise
             near_tie = (np.min(np.abs(g["pos_err"][t] - pos_thr)) < 2e-6) or (np.min(np.abs(g["ori_err"][t] - ori_thr)) < 2e-6) \
-                or abs(g["pos_err"][t] - g["pos_err"][t - 1] if t else 1.0) < 2e-7
+                or (t > 0 and abs(g["pos_err"][t] - g["pos_err"][t - 1]) < 1e-6)
             tainted = tainted or near_tie
         if not tainted:
             assert done_b == gold_done, f"{ctx}: done {done_b} vs {gold_done}"
