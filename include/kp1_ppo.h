@@ -1,0 +1,116 @@
+/*
+ * kp1_ppo.h -- C ABI of the PPO-side device kernels of the MI355X kinematic_phase1 engine.
+ *
+ * The reference delegates PPO to stable_baselines3.PPO("MultiInputPolicy") (call sites:
+ * kinematic_phase1/train_workspace_expansion.py:199,232; training/train_dock_policy.py:99,102).
+ * SB3 2.8.0 (final_codes_docker/Dockerfile.demo:32) is absent from the reference tree and from this
+ * image, so these kernels restate SB3's published semantics ("parity unpinned")
+ * and are checked against plain PyTorch fp32 references of the same ops (tests/test_ppo_kernels_gpu.py).
+ *
+ * All pointers are HIP device pointers unless named *_host.  Layout [T][N] = time-major.
+ * Every function returns KP1_OK or a negative kp1_status (kp1.h); text via kp1_last_error().
+ */
+#ifndef KP1_PPO_H
+#define KP1_PPO_H
+
+#include <stdint.h>
+
+#include "kp1.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* RolloutBuffer.compute_returns_and_advantage (SB3 common/buffers.py): reverse GAE(lambda) scan, one lane per env.
+ *   delta_t = r_t + gamma * V_{t+1} * (1 - done_t) - V_t ;  A_t = delta_t + gamma*lambda*(1 - done_t) * A_{t+1}
+ *   V_T = last_values ; returns = A + V.   done_t = (done bits of step t) & (TERMINATED|TRUNCATED).
+ * rewards/values/advantages/returns f32 [T][N]; dones u8 [T][N] (KP1_DONE_* bits as written by kp1_step). */
+int kp1_gae_scan(int32_t device, const float* rewards, const float* values, const uint8_t* dones, const float* last_values,
+                 float gamma, float gae_lambda, float* advantages, float* returns, int32_t T, int32_t N, void* stream);
+
+/* Time-limit bootstrap (SB3 on_policy_algorithm.collect_rollouts): rewards[t][i] += gamma * terminal_values[t][i]
+ * where step t of env i was truncated and not terminated. */
+int kp1_bootstrap_truncated(int32_t device, float* rewards, const float* terminal_values, const uint8_t* dones, float gamma,
+                            int64_t count, void* stream);
+
+/* ---- device-resident PointCurriculumCallback (kinematic_phase1/training/callbacks.py:32-101) --------------------
+ * The callback scans (done, info["success"]) in env order after every VecEnv step and may promote the stage for ALL
+ * envs; resets inside that step already happened with the old stage.  Keeping the tracker on the device removes the
+ * per-step host sync: kp1_curriculum_observe runs after each kp1_step on the same stream and publishes the stage in
+ * device memory, from which the next kp1_step reads it (kp1_bind_stage_ptr). */
+#define KP1_CURRICULUM_MAX_WINDOW 1024
+#define KP1_CURRICULUM_MAX_HISTORY 64
+typedef struct kp1_curriculum_event {
+  int64_t total_timesteps; /* env steps taken (all ranks) when the promotion fired, like history["total_timesteps"] */
+  int32_t from_stage, to_stage;
+  double trigger_success_rate;
+} kp1_curriculum_event;
+typedef struct kp1_curriculum_state {
+  int32_t stage_index;          /* current_stage_index; first word so an env kernel can read it as int32 */
+  int32_t stage_episode_count;
+  int32_t ring_len, ring_head;
+  int32_t window_episodes, min_episodes_per_stage, max_stage_index, n_events;
+  double success_rate_threshold;
+  int64_t num_timesteps;
+  int32_t ring[KP1_CURRICULUM_MAX_WINDOW];
+  kp1_curriculum_event events[KP1_CURRICULUM_MAX_HISTORY];
+} kp1_curriculum_state;
+
+/* allocate + initialise a tracker in device memory (callbacks.py:33-51) */
+int kp1_curriculum_create(int32_t device, double success_rate_threshold, int32_t window_episodes, int32_t min_episodes_per_stage,
+                          int32_t max_stage_index, int32_t initial_stage_index, kp1_curriculum_state** out_dev);
+int kp1_curriculum_destroy(int32_t device, kp1_curriculum_state* st_dev);
+/* _on_step (callbacks.py:71-92): consume dones[0..n) (KP1_DONE_* bits) in index order; steps_per_call = env steps this
+ * call represents (n_envs * world_size) for the num_timesteps clock. */
+int kp1_curriculum_observe(int32_t device, kp1_curriculum_state* st_dev, const uint8_t* dones, int32_t n, int32_t steps_per_call, void* stream);
+int kp1_curriculum_read(int32_t device, const kp1_curriculum_state* st_dev, kp1_curriculum_state* out_host, void* stream);
+/* make kp1_step take its curriculum stage from *stage_dev (e.g. &tracker->stage_index) instead of kp1_set_stage */
+int kp1_bind_stage_ptr(kp1_env* env, const int32_t* stage_dev);
+
+/* ---- actor-critic MLP on the matrix cores (fp32-in / fp32-accumulate MFMA, exact f32) ---------------------------
+ * SB3 MultiInputActorCriticPolicy with net_arch pi = vf = [H, H], tanh:
+ *   h1 = tanh(x W1^T + b1); h2 = tanh(h1 W2^T + b2); mean = h2p Wa^T + ba (7); value = h2v Wv^T + bv (1).
+ * Both nets (index 0 = policy, 1 = value) run in one launch (grid.z).  H must be a multiple of 128 or equal to 64.
+ * Kernel-format weights ("kw", see kp1_mlp_pack_weights) hold W1 zero-padded to 64 input columns, W2 and W2^T. */
+#define KP1_MLP_IN 56
+#define KP1_MLP_IN_PAD 64
+#define KP1_MLP_ACT 7
+
+typedef struct kp1_mlp kp1_mlp; /* workspace: packed weights, activations, gradients for up to max_batch rows */
+
+int kp1_mlp_create(int32_t device, int32_t hidden, int32_t max_batch, kp1_mlp** out);
+int kp1_mlp_destroy(kp1_mlp* m);
+/* number of f32 parameters in SB3 state_dict order (log_std, pi.0.w, pi.0.b, pi.2.w, pi.2.b, vf.0.w, ..., action_net.w/b, value_net.w/b) */
+int64_t kp1_mlp_num_params(int32_t hidden);
+/* repack the flat SB3-order parameter vector into kernel-format weights (call after every optimiser step) */
+int kp1_mlp_pack_weights(kp1_mlp* m, const float* params, void* stream);
+
+/* policy.forward for a rollout step: obs f32 [n][obs_stride] (first 56 columns used; obs_stride 56 or 64 with zero pad),
+ * noise f32 [n][7] ~ N(0,1) or NULL (deterministic).  Outputs (any may be NULL):
+ *   mean[n][7], value[n], action[n][7] = mean + exp(log_std) * noise, clipped_action[n][7] = clip(action, -1, 1),
+ *   log_prob[n] = sum_d N(action_d; mean_d, std_d). */
+int kp1_mlp_forward(kp1_mlp* m, const float* obs, int32_t obs_stride, int32_t n, const float* noise, float* mean, float* value,
+                    float* action, float* clipped_action, float* log_prob, void* stream);
+
+/* one PPO minibatch: forward + loss + full backward.  Rows are gathered through idx (int64 [n] into the [total] axis, or
+ * NULL = rows 0..n).  grad_out f32 [num_params] receives d loss / d params in SB3 order (overwritten), with
+ *   loss = sum_i[-min(r_i A_i, clip(r_i, 1-c, 1+c) A_i)] * inv_count + vf_coef * sum_i (R_i - V_i)^2 * inv_count - ent_coef * H,
+ * r = exp(logp - old_logp), H = entropy of the diagonal Gaussian (state independent).
+ * stats_out f32[4] += (policy_loss, value_loss, entropy, approx_kl) of this minibatch. */
+int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const int64_t* idx, int32_t n, const float* actions,
+                      const float* old_log_prob, const float* advantages, const float* returns, float adv_mean, float adv_inv_std,
+                      const float* adv_stats_dev, float clip_range, float ent_coef, float vf_coef, float inv_count, float* grad_out,
+                      float* stats_out, void* stream);
+
+/* clip_grad_norm_(max_norm) + Adam(beta 0.9/0.999, eps) step on the flat vectors, then repack the kernel-format weights.
+ * step = 1-based Adam step count. */
+int kp1_mlp_adam_step(kp1_mlp* m, float* params, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float eps,
+                      float max_grad_norm, int32_t step, void* stream);
+
+/* make kp1_step / kp1_reset write observation rows with this stride (56 default, 64 = MFMA-friendly, zero padded) */
+int kp1_set_obs_stride(kp1_env* env, int32_t stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KP1_PPO_H */

@@ -17,7 +17,9 @@
 #include <string>
 #include <vector>
 
+#include "../../include/kp1_ppo.h"
 #include "kp1_device.hpp"
+#include "kp1_host.hpp"
 
 using namespace kp1;
 
@@ -249,6 +251,7 @@ struct StepArgs {
   R* comps;              // [n_components][N] or nullptr
   int auto_reset;
   int stage_index;
+  const int32_t* stage_ptr;  // device-resident curriculum stage (kp1_bind_stage_ptr) or nullptr
 };
 
 template <typename R, int MODE, bool COMPS>
@@ -393,7 +396,9 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
     // VecEnv auto-reset: keep the finished episode's last observation + info norms, then reset in place.
     if (a.terminal_obs) store_obs_row(a.terminal_obs, i, o);
     ResetOptsDev none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    reset_env<R, MODE>(st, cfg, *a.smp, a.handoff, none, a.stage_index, i, o);
+    int stage = a.stage_index;
+    if (a.stage_ptr) stage = kp_clipi(*a.stage_ptr, 0, kp_maxi(a.smp->n_stages - 1, 0));
+    reset_env<R, MODE>(st, cfg, *a.smp, a.handoff, none, stage, i, o);
     // info of the finished episode stays readable (SB3 infos[i] of a done env is the terminal info)
     st.r(F_POS_ERR, i) = curr_pos;
     st.r(F_ORI_ERR, i) = curr_ori;
@@ -536,17 +541,6 @@ __global__ void kp1_get_state_kernel(const EnvState<R> st, double* q, double* dq
 // host side
 // ============================================================================================
 namespace {
-
-thread_local std::string g_last_error;
-int fail(int code, const std::string& msg) {
-  g_last_error = msg;
-  return code;
-}
-#define HIP_TRY(expr)                                                                                  \
-  do {                                                                                                 \
-    hipError_t _e = (expr);                                                                            \
-    if (_e != hipSuccess) return fail(KP1_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-  } while (0)
 
 // ---- numpy SeedSequence + PCG64 seeding (numpy/random/bit_generator.pyx, src/pcg64/pcg64.h) ----
 uint32_t ss_hashmix(uint32_t value, uint32_t& hash_const) {
@@ -773,6 +767,7 @@ struct kp1_env {
   kp1_handoff_state* dev_handoff = nullptr;
   int32_t n_handoff = 0;
   double* opt_scratch = nullptr;  // 4*[N][7] + [N][6] doubles for explicit reset options / set_state
+  const int32_t* stage_ptr = nullptr;  // kp1_bind_stage_ptr
   void* comps = nullptr;          // R[64][N] when enabled
   bool comps_enabled = false;
   size_t real_size() const { return real_type == KP1_REAL_F64 ? 8 : 4; }
@@ -843,6 +838,7 @@ int launch_step(kp1_env* e, const void* actions, float* obs, void* reward, uint8
   a.comps = (R*)e->comps;
   a.auto_reset = auto_reset;
   a.stage_index = e->stage;
+  a.stage_ptr = e->cfg.curriculum_enabled ? e->stage_ptr : nullptr;
   const int block = block_for(e->n);
   const dim3 grid((unsigned)((e->n + block - 1) / block));
   const bool comps = e->comps_enabled && e->comps;
@@ -972,6 +968,11 @@ int kp1_set_stage(kp1_env* e, int32_t stage_index) {
   if (!e->cfg.curriculum_enabled) return KP1_OK;  // arm_kinematic_env.py:447-448
   int hi = e->cfg.n_stages - 1;
   e->stage = stage_index < 0 ? 0 : (stage_index > hi ? hi : stage_index);
+  return KP1_OK;
+}
+int kp1_bind_stage_ptr(kp1_env* e, const int32_t* stage_dev) {
+  if (!e) return fail(KP1_ERR_INVALID, "env is NULL");
+  e->stage_ptr = stage_dev;
   return KP1_OK;
 }
 int kp1_get_stage(const kp1_env* e, int32_t* stage_index) {

@@ -1,0 +1,73 @@
+"""Python handle on the MFMA actor-critic kernels (include/kp1_ppo.h, csrc/kp1_mlp.hip)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import native
+
+OBS_DIM, OBS_PAD, ACT_DIM = 56, 64, 7
+
+
+def _p(t: torch.Tensor | None):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class MlpKernels:
+    def __init__(self, hidden: int, device: torch.device, max_batch: int = 8192) -> None:
+        self.L = native.load()
+        L = self.L
+        vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+        L.kp1_mlp_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+        L.kp1_mlp_destroy.argtypes = [vp]
+        L.kp1_mlp_num_params.argtypes = [i32]
+        L.kp1_mlp_num_params.restype = C.c_int64
+        L.kp1_mlp_pack_weights.argtypes = [vp, vp, vp]
+        L.kp1_mlp_forward.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+        L.kp1_mlp_loss_grad.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, f32, f32, vp, f32, f32, f32, f32, vp, vp, vp]
+        L.kp1_mlp_adam_step.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, i32, vp]
+        self.hidden = hidden
+        self.device = device
+        self.max_batch = int(max_batch)
+        self._h = vp()
+        native.check(L.kp1_mlp_create(device.index or 0, hidden, self.max_batch, C.byref(self._h)))
+        self.num_params = int(L.kp1_mlp_num_params(hidden))
+
+    def close(self) -> None:
+        if self._h.value:
+            self.L.kp1_mlp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def pack(self, flat_params: torch.Tensor) -> None:
+        assert flat_params.numel() == self.num_params and flat_params.dtype == torch.float32 and flat_params.is_contiguous()
+        native.check(self.L.kp1_mlp_pack_weights(self._h, _p(flat_params), self._stream()))
+
+    def forward(self, obs: torch.Tensor, *, noise=None, mean=None, value=None, action=None, clipped=None, log_prob=None) -> None:
+        """obs [n, 56|64] contiguous f32; outputs written in place (None = skip)."""
+        n, stride = obs.shape[0], obs.shape[1]
+        assert obs.is_contiguous() and obs.dtype == torch.float32
+        native.check(self.L.kp1_mlp_forward(self._h, _p(obs), stride, n, _p(noise), _p(mean), _p(value), _p(action), _p(clipped), _p(log_prob), self._stream()))
+
+    def mean_value(self, obs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        n = obs.shape[0]
+        mean = torch.empty((n, ACT_DIM), dtype=torch.float32, device=obs.device)
+        value = torch.empty(n, dtype=torch.float32, device=obs.device)
+        for s in range(0, n, self.max_batch):
+            e = min(s + self.max_batch, n)
+            self.forward(obs[s:e], mean=mean[s:e], value=value[s:e])
+        return mean, value
+
+    def loss_grad(self, obs: torch.Tensor, idx: torch.Tensor | None, n: int, actions, old_logp, adv, ret, *, clip_range: float, ent_coef: float,
+                  vf_coef: float, inv_count: float, grad_out: torch.Tensor, stats_out: torch.Tensor | None, adv_stats: torch.Tensor | None = None,
+                  normalize: bool = True) -> None:
+        assert obs.is_contiguous() and grad_out.numel() == self.num_params
+        inv_std = 0.0 if normalize else -1.0
+        native.check(self.L.kp1_mlp_loss_grad(self._h, _p(obs), obs.shape[-1], _p(idx), n, _p(actions), _p(old_logp), _p(adv), _p(ret), 0.0, inv_std,
+                                              _p(adv_stats), clip_range, ent_coef, vf_coef, inv_count, _p(grad_out), _p(stats_out), self._stream()))
+
+    def adam_step(self, params, grad, exp_avg, exp_avg_sq, *, lr: float, eps: float, max_grad_norm: float, step: int) -> None:
+        native.check(self.L.kp1_mlp_adam_step(self._h, _p(params), _p(grad), _p(exp_avg), _p(exp_avg_sq), lr, eps, max_grad_norm, step, self._stream()))

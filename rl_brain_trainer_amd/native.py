@@ -81,6 +81,14 @@ def load() -> C.CDLL:
     L.kp1_rng_set.argtypes = [vp, vp]
     L.kp1_fk_pose6.argtypes = [i32, i32, vp, vp, i64, vp]
     L.kp1_rng_seed_state.argtypes = [u64, C.POINTER(kcfg.RngState)]
+    f32 = C.c_float
+    L.kp1_gae_scan.argtypes = [i32, vp, vp, vp, vp, f32, f32, vp, vp, i32, i32, vp]
+    L.kp1_bootstrap_truncated.argtypes = [i32, vp, vp, vp, f32, i64, vp]
+    L.kp1_curriculum_create.argtypes = [i32, C.c_double, i32, i32, i32, i32, C.POINTER(vp)]
+    L.kp1_curriculum_destroy.argtypes = [i32, vp]
+    L.kp1_curriculum_observe.argtypes = [i32, vp, vp, i32, i32, vp]
+    L.kp1_curriculum_read.argtypes = [i32, vp, vp, vp]
+    L.kp1_bind_stage_ptr.argtypes = [vp, vp]
     if L.kp1_config_size() != C.sizeof(kcfg.Kp1Config):
         raise Kp1Error(f"kp1_config layout mismatch: library {L.kp1_config_size()} vs binding {C.sizeof(kcfg.Kp1Config)}")
     _lib = L

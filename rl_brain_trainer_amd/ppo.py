@@ -1,0 +1,390 @@
+"""PPO rollout-and-update loop on one MI355X (or one rank of a data-parallel job).
+
+Restates stable_baselines3.PPO("MultiInputPolicy") as the reference drives it
+(kinematic_phase1/train_workspace_expansion.py:175-232, training/train_dock_policy.py:86-102):
+
+* policy: CombinedExtractor (56 floats, alphabetical key order) -> separate tanh MLPs ``pi`` / ``vf``
+  (SB3 default 2x64; BASELINE config 2 asks 2x256) -> ``action_net`` (7) / ``value_net`` (1),
+  state-independent ``log_std`` (init 0), orthogonal init (gain sqrt2 / 0.01 / 1);
+* rollout: sample a ~ N(mean, exp(log_std)), store the unclipped action, clip to [-1, 1] for the env,
+  bootstrap truncated episodes with gamma * V(terminal_observation), GAE(lambda);
+* update: n_epochs x shuffled minibatches, per-minibatch advantage normalisation, clipped surrogate +
+  0.5 * MSE value loss - ent_coef * entropy, global grad-norm clip 0.5, Adam(eps=1e-5).
+
+SB3 itself is not in the reference tree nor in this image: these semantics are "parity unpinned"
+ and are tested against plain-PyTorch references of each op.
+
+Everything stays on the device: the env kernel writes straight into the rollout buffer, the curriculum
+tracker is a device kernel, and the only host synchronisation per iteration is the logging read-back.
+Under torch.distributed (backend "nccl" = RCCL) env ranges are sharded by rank and gradients are summed
+with one flat all-reduce per optimiser step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import time
+from dataclasses import dataclass, field
+from typing import Any
+
+import torch
+
+from . import config as kcfg
+from . import native
+from .curriculum import PointCurriculum
+from .vec_env import ArmKinematicVecEnv
+
+OBS_DIM = kcfg.OBS_DIM
+ACT_DIM = kcfg.NJ
+
+
+@dataclass
+class PPOConfig:
+    """algorithms.ppo block of the YAML (ppo_default.yaml) + SB3 defaults for what the YAML leaves out."""
+
+    learning_rate: float = 3e-4
+    n_steps: int = 2048
+    batch_size: int = 256
+    n_epochs: int = 10
+    gamma: float = 0.99
+    gae_lambda: float = 0.95
+    clip_range: float = 0.2
+    ent_coef: float = 0.0
+    vf_coef: float = 0.5
+    max_grad_norm: float = 0.5
+    adam_eps: float = 1e-5
+    seed: int = 0
+    hidden: int = 64            # SB3 default net_arch = dict(pi=[64, 64], vf=[64, 64])
+    normalize_advantage: bool = True
+    total_timesteps: int = 100_000
+
+    @classmethod
+    def from_algo_kwargs(cls, kwargs: dict[str, Any], **overrides: Any) -> "PPOConfig":
+        known = {f for f in cls.__dataclass_fields__}
+        data = {k: v for k, v in kwargs.items() if k in known}
+        unknown = set(kwargs) - known
+        if unknown:
+            raise TypeError(f"PPO.__init__() got unexpected keyword arguments {sorted(unknown)}")
+        data.update(overrides)
+        return cls(**data)
+
+
+def param_spec(hidden: int) -> list[tuple[str, tuple[int, ...]]]:
+    """SB3 MultiInputActorCriticPolicy.state_dict() keys/shapes for net_arch pi=vf=[hidden, hidden]."""
+    H = hidden
+    return [
+        ("log_std", (ACT_DIM,)),
+        ("mlp_extractor.policy_net.0.weight", (H, OBS_DIM)), ("mlp_extractor.policy_net.0.bias", (H,)),
+        ("mlp_extractor.policy_net.2.weight", (H, H)), ("mlp_extractor.policy_net.2.bias", (H,)),
+        ("mlp_extractor.value_net.0.weight", (H, OBS_DIM)), ("mlp_extractor.value_net.0.bias", (H,)),
+        ("mlp_extractor.value_net.2.weight", (H, H)), ("mlp_extractor.value_net.2.bias", (H,)),
+        ("action_net.weight", (ACT_DIM, H)), ("action_net.bias", (ACT_DIM,)),
+        ("value_net.weight", (1, H)), ("value_net.bias", (1,)),
+    ]
+
+
+class ActorCritic:
+    """Flat fp32 parameter buffer with SB3-named views."""
+
+    def __init__(self, hidden: int, device: torch.device, seed: int = 0) -> None:
+        self.hidden = hidden
+        self.device = device
+        self.spec = param_spec(hidden)
+        self.numel = sum(math.prod(s) for _, s in self.spec)
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.views: dict[str, torch.Tensor] = {}
+        off = 0
+        for name, shape in self.spec:
+            n = math.prod(shape)
+            self.views[name] = self.flat[off:off + n].view(shape)
+            off += n
+        self._init(seed)
+
+    def _init(self, seed: int) -> None:
+        g = torch.Generator(device="cpu").manual_seed(int(seed))
+        gains = {"mlp_extractor": math.sqrt(2.0), "action_net": 0.01, "value_net": 1.0}
+        for name, shape in self.spec:
+            if name.endswith("weight"):
+                w = torch.empty(shape, dtype=torch.float32)
+                torch.nn.init.orthogonal_(w, gain=gains[name.split(".")[0]], generator=g)
+                self.views[name].copy_(w)
+            else:
+                self.views[name].zero_()  # biases and log_std start at 0
+
+    def state_dict(self) -> dict[str, torch.Tensor]:
+        return {k: v.detach().clone().cpu() for k, v in self.views.items()}
+
+    def load_state_dict(self, sd: dict[str, torch.Tensor]) -> None:
+        for name, shape in self.spec:
+            t = sd[name]
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError(f"{name}: checkpoint shape {tuple(t.shape)} != {tuple(shape)}")
+            self.views[name].copy_(t.to(self.device, torch.float32))
+
+
+def mlp_forward(P: dict[str, torch.Tensor], obs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """mean[B,7], value[B] of the SB3 MlpExtractor + heads (plain torch; also the reference for the HIP kernels)."""
+    hp = torch.tanh(torch.addmm(P["mlp_extractor.policy_net.0.bias"], obs, P["mlp_extractor.policy_net.0.weight"].t()))
+    hp = torch.tanh(torch.addmm(P["mlp_extractor.policy_net.2.bias"], hp, P["mlp_extractor.policy_net.2.weight"].t()))
+    mean = torch.addmm(P["action_net.bias"], hp, P["action_net.weight"].t())
+    hv = torch.tanh(torch.addmm(P["mlp_extractor.value_net.0.bias"], obs, P["mlp_extractor.value_net.0.weight"].t()))
+    hv = torch.tanh(torch.addmm(P["mlp_extractor.value_net.2.bias"], hv, P["mlp_extractor.value_net.2.weight"].t()))
+    value = torch.addmm(P["value_net.bias"], hv, P["value_net.weight"].t()).squeeze(-1)
+    return mean, value
+
+
+LOG_SQRT_2PI = 0.5 * math.log(2.0 * math.pi)
+
+
+def gaussian_log_prob(actions: torch.Tensor, mean: torch.Tensor, log_std: torch.Tensor) -> torch.Tensor:
+    z = (actions - mean) * torch.exp(-log_std)
+    return (-0.5 * z * z - log_std - LOG_SQRT_2PI).sum(-1)
+
+
+class Dist:
+    """torch.distributed glue (backend nccl = RCCL on ROCm, gloo on CPU tests).  world_size 1 = no-ops."""
+
+    def __init__(self) -> None:
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world_size = dist.get_world_size() if self.enabled else 1
+        self.rank = dist.get_rank() if self.enabled else 0
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        if self.enabled:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t
+
+    def all_gather_bytes(self, t: torch.Tensor) -> torch.Tensor:
+        if not self.enabled:
+            return t
+        out = torch.empty((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out, t)
+        return out.view(-1)
+
+    def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
+        if self.enabled:
+            self.dist.broadcast(t, src)
+        return t
+
+
+class PPO:
+    def __init__(self, env: ArmKinematicVecEnv, cfg: PPOConfig, *, curriculum: PointCurriculum | None = None,
+                 dist: Dist | None = None, backend: str = "hip") -> None:
+        self.env = env
+        self.cfg = cfg
+        self.device = env.device
+        self.dist = dist or Dist()
+        self.backend = backend
+        self.L = native.load()
+        self.n_envs = env.n_envs
+        self.policy = ActorCritic(cfg.hidden, self.device, seed=cfg.seed)
+        self.dist.broadcast(self.policy.flat)
+        self.adam_m = torch.zeros_like(self.policy.flat)
+        self.adam_v = torch.zeros_like(self.policy.flat)
+        self.adam_t = 0
+        self.curriculum = curriculum
+        if curriculum is not None:
+            curriculum.attach(env)
+        T, N = cfg.n_steps, self.n_envs
+        dev = self.device
+        self.obs_buf = torch.zeros((T + 1, N, OBS_DIM), dtype=torch.float32, device=dev)
+        self.term_obs_buf = torch.zeros((T, N, OBS_DIM), dtype=torch.float32, device=dev)
+        self.act_buf = torch.zeros((T, N, ACT_DIM), dtype=torch.float32, device=dev)
+        self.clip_act = torch.zeros((N, ACT_DIM), dtype=torch.float32, device=dev)
+        self.logp_buf = torch.zeros((T, N), dtype=torch.float32, device=dev)
+        self.val_buf = torch.zeros((T, N), dtype=torch.float32, device=dev)
+        self.rew_buf = torch.zeros((T, N), dtype=torch.float32, device=dev)
+        self.done_buf = torch.zeros((T, N), dtype=torch.uint8, device=dev)
+        self.adv_buf = torch.zeros((T, N), dtype=torch.float32, device=dev)
+        self.ret_buf = torch.zeros((T, N), dtype=torch.float32, device=dev)
+        self.gen = torch.Generator(device=dev).manual_seed(int(cfg.seed) + 7919 * self.dist.rank)
+        self.num_timesteps = 0
+        self._needs_reset = True
+        self.last_stats: dict[str, float] = {}
+        if env.dtype != torch.float32:
+            raise ValueError("PPO drives the production f32 env")
+        self._mlp = None
+        if backend == "hip":
+            from . import mlp as _mlp
+
+            self._mlp = _mlp.MlpKernels(cfg.hidden, self.device)
+
+    # ------------------------------------------------------------------ policy evaluation
+    def _forward(self, obs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        if self._mlp is not None:
+            return self._mlp.forward(self.policy, obs)
+        return mlp_forward(self.policy.views, obs)
+
+    def predict(self, obs: torch.Tensor, deterministic: bool = True) -> torch.Tensor:
+        """model.predict(obs, deterministic): mean (or a sample) clipped to the action space (eval_three_stage.py:25-27)."""
+        with torch.no_grad():
+            mean, _ = self._forward(obs)
+            if not deterministic:
+                mean = mean + torch.exp(self.policy.views["log_std"]) * torch.randn(mean.shape, device=mean.device, generator=self.gen)
+            return mean.clamp(-1.0, 1.0)
+
+    def predict_unclipped(self, obs: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            return self._forward(obs)[0]
+
+    # ------------------------------------------------------------------ rollout
+    @torch.no_grad()
+    def collect_rollouts(self) -> None:
+        cfg, env = self.cfg, self.env
+        T, N = cfg.n_steps, self.n_envs
+        if self._needs_reset:
+            self.obs_buf[0].copy_(env.reset())
+            self._needs_reset = False
+        else:
+            self.obs_buf[0].copy_(self.obs_buf[T])
+        log_std = self.policy.views["log_std"]
+        std = torch.exp(log_std)
+        world = self.dist.world_size
+        for t in range(T):
+            mean, value = self._forward(self.obs_buf[t])
+            noise = torch.randn((N, ACT_DIM), dtype=torch.float32, device=self.device, generator=self.gen)
+            action = torch.addcmul(mean, std, noise)
+            self.act_buf[t].copy_(action)
+            self.logp_buf[t].copy_((-0.5 * noise * noise - log_std - LOG_SQRT_2PI).sum(-1))
+            self.val_buf[t].copy_(value)
+            torch.clamp(action, -1.0, 1.0, out=self.clip_act)
+            env.step_into(self.clip_act, self.obs_buf[t + 1], self.rew_buf[t], self.done_buf[t], self.term_obs_buf[t], True)
+            if self.curriculum is not None:
+                dones = self.dist.all_gather_bytes(self.done_buf[t])
+                self.curriculum.observe(dones, N * world)
+        self.num_timesteps += T * N * world
+        # time-limit bootstrap: r += gamma * V(terminal_obs) on truncated steps (one batched critic pass, no host sync)
+        _, tv = self._forward(self.term_obs_buf.view(T * N, OBS_DIM))
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        dev = self.device.index or 0
+        native.check(self.L.kp1_bootstrap_truncated(dev, C.c_void_p(self.rew_buf.data_ptr()), C.c_void_p(tv.data_ptr()),
+                                                    C.c_void_p(self.done_buf.data_ptr()), cfg.gamma, T * N, C.c_void_p(stream)))
+        _, last_v = self._forward(self.obs_buf[T])
+        last_v = last_v.contiguous()
+        native.check(self.L.kp1_gae_scan(dev, C.c_void_p(self.rew_buf.data_ptr()), C.c_void_p(self.val_buf.data_ptr()),
+                                         C.c_void_p(self.done_buf.data_ptr()), C.c_void_p(last_v.data_ptr()), cfg.gamma, cfg.gae_lambda,
+                                         C.c_void_p(self.adv_buf.data_ptr()), C.c_void_p(self.ret_buf.data_ptr()), T, N, C.c_void_p(stream)))
+
+    # ------------------------------------------------------------------ update
+    def train(self) -> None:
+        cfg = self.cfg
+        T, N = cfg.n_steps, self.n_envs
+        total = T * N
+        obs = self.obs_buf[:T].view(total, OBS_DIM)
+        act = self.act_buf.view(total, ACT_DIM)
+        old_logp = self.logp_buf.view(total)
+        adv = self.adv_buf.view(total)
+        ret = self.ret_buf.view(total)
+        world = self.dist.world_size
+        local_bs = max(cfg.batch_size // world, 1)
+        stats = torch.zeros(4, device=self.device)
+        n_updates = 0
+        for _epoch in range(cfg.n_epochs):
+            perm = torch.randperm(total, device=self.device, generator=self.gen)
+            for start in range(0, total, local_bs):
+                idx = perm[start:start + local_bs]
+                loss_terms = self._minibatch_step(obs[idx], act[idx], old_logp[idx], adv[idx], ret[idx])
+                stats += loss_terms
+                n_updates += 1
+        self.last_stats = dict(zip(("policy_loss", "value_loss", "entropy", "approx_kl"), (stats / max(n_updates, 1)).tolist()))
+        self.last_stats["n_updates"] = n_updates
+
+    def _normalize_adv(self, adv: torch.Tensor) -> torch.Tensor:
+        if not self.cfg.normalize_advantage or adv.numel() * self.dist.world_size <= 1:
+            return adv
+        if not self.dist.enabled:
+            return (adv - adv.mean()) / (adv.std() + 1e-8)
+        # GPU-count invariant normalisation: global (sum, sum^2, count)
+        s = torch.stack([adv.sum(), (adv * adv).sum(), torch.tensor(float(adv.numel()), device=adv.device)])
+        self.dist.all_reduce_sum(s)
+        mean = s[0] / s[2]
+        var = (s[1] - s[2] * mean * mean) / (s[2] - 1.0)
+        return (adv - mean) / (var.clamp_min(0).sqrt() + 1e-8)
+
+    def _minibatch_step(self, obs, act, old_logp, adv, ret) -> torch.Tensor:
+        cfg = self.cfg
+        adv = self._normalize_adv(adv)
+        if self._mlp is not None:
+            grad, terms = self._mlp.loss_and_grad(self.policy, obs, act, old_logp, adv, ret, cfg.clip_range, cfg.ent_coef, cfg.vf_coef,
+                                                  1.0 / (obs.shape[0] * self.dist.world_size))
+        else:
+            grad, terms = self._torch_loss_and_grad(obs, act, old_logp, adv, ret)
+        self.dist.all_reduce_sum(grad)
+        self._clip_and_adam(grad)
+        return terms
+
+    def _torch_loss_and_grad(self, obs, act, old_logp, adv, ret) -> tuple[torch.Tensor, torch.Tensor]:
+        cfg = self.cfg
+        flat = self.policy.flat.detach().requires_grad_(True)
+        P, off = {}, 0
+        for name, shape in self.policy.spec:
+            n = math.prod(shape)
+            P[name] = flat[off:off + n].view(shape)
+            off += n
+        mean, value = mlp_forward(P, obs)
+        log_std = P["log_std"]
+        logp = gaussian_log_prob(act, mean, log_std)
+        ratio = torch.exp(logp - old_logp)
+        denom = float(obs.shape[0] * self.dist.world_size)
+        pl = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - cfg.clip_range, 1 + cfg.clip_range)).sum() / denom
+        vl = ((ret - value) ** 2).sum() / denom
+        ent = (0.5 + LOG_SQRT_2PI + log_std).sum()  # per-sample entropy is constant: mean == value
+        loss = pl + cfg.vf_coef * vl - cfg.ent_coef * ent / self.dist.world_size
+        (grad,) = torch.autograd.grad(loss, flat)
+        with torch.no_grad():
+            kl = ((ratio - 1) - (logp - old_logp)).mean()
+            terms = torch.stack([pl.detach(), vl.detach(), ent.detach(), kl])
+        return grad, terms
+
+    def _clip_and_adam(self, grad: torch.Tensor) -> None:
+        cfg = self.cfg
+        with torch.no_grad():
+            norm = torch.linalg.vector_norm(grad)
+            scale = torch.clamp(cfg.max_grad_norm / (norm + 1e-6), max=1.0)  # clip_grad_norm_
+            grad = grad * scale
+            self.adam_t += 1
+            b1, b2 = 0.9, 0.999
+            self.adam_m.mul_(b1).add_(grad, alpha=1 - b1)
+            self.adam_v.mul_(b2).addcmul_(grad, grad, value=1 - b2)
+            bc1 = 1 - b1 ** self.adam_t
+            bc2 = 1 - b2 ** self.adam_t
+            denom = (self.adam_v.sqrt() / math.sqrt(bc2)).add_(cfg.adam_eps)
+            self.policy.flat.addcdiv_(self.adam_m, denom, value=-cfg.learning_rate / bc1)
+
+    # ------------------------------------------------------------------ driver
+    def learn(self, total_timesteps: int | None = None, log_every: int = 0) -> "PPO":
+        total = int(total_timesteps if total_timesteps is not None else self.cfg.total_timesteps)
+        start_steps = self.num_timesteps
+        it = 0
+        t0 = time.time()
+        while self.num_timesteps - start_steps < total:
+            self.collect_rollouts()
+            self.train()
+            it += 1
+            if log_every and it % log_every == 0 and self.dist.rank == 0:
+                dt = time.time() - t0
+                stage = self.curriculum.read().stage_index if self.curriculum is not None else -1
+                print(f"[ppo] it={it} steps={self.num_timesteps} fps={(self.num_timesteps - start_steps) / dt:,.0f} stage={stage} "
+                      f"rew={self.rew_buf.mean().item():.4f} {self.last_stats}", flush=True)
+        return self
+
+
+def smoke() -> dict[str, Any]:
+    """tiny rollout + update on cuda:0 for __graft_entry__.smoke()"""
+    cfg_dict = kcfg.load_workspace_expansion_config(kcfg.builtin_config_dir() / "workspace_expansion_bigtrain.yaml")
+    env_cfg = kcfg.to_env_config(cfg_dict)
+    env = ArmKinematicVecEnv(env_cfg, 256, seed=806)
+    env.set_curriculum_stage(5)
+    ppo = PPO(env, PPOConfig(n_steps=16, batch_size=1024, n_epochs=2, hidden=256, learning_rate=6e-6, gamma=0.995, clip_range=0.1, ent_coef=3e-4, seed=806))
+    before = ppo.policy.flat.clone()
+    ppo.collect_rollouts()
+    ppo.train()
+    torch.cuda.synchronize()
+    delta = (ppo.policy.flat - before).abs().max().item()
+    assert math.isfinite(delta) and delta > 0.0, "PPO update did not change the parameters"
+    assert torch.isfinite(ppo.adv_buf).all()
+    env.close()
+    return {"ppo_param_delta": delta, "ppo_backend": ppo.backend}

@@ -1,0 +1,199 @@
+"""PPO-side HIP kernels vs plain PyTorch fp32 references of the same ops (SB3 semantics are 'parity unpinned':
+SB3 2.8.0 is not in the reference tree or this image; see include/kp1_ppo.h).
+
+Tolerances (fp32): the MFMA path sums K in a different order than torch/rocBLAS, so forward values agree to
+~1e-5 relative and gradients to ~2e-4 of their scale; both are written next to each assert."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from rl_brain_trainer_amd import ppo as P
+from rl_brain_trainer_amd.curriculum import PointCurriculum
+from rl_brain_trainer_amd.mlp import MlpKernels
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _policy(hidden=256, seed=3, scale_heads=True):
+    pol = P.ActorCritic(hidden, DEV, seed=seed)
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    # non-trivial biases / log_std so every gradient path is exercised
+    for name, _ in pol.spec:
+        if name.endswith("bias"):
+            pol.views[name].copy_(0.1 * torch.randn(pol.views[name].shape, generator=g))
+    pol.views["log_std"].copy_(torch.tensor([-0.3, 0.1, -0.5, 0.0, 0.2, -0.1, -0.7]))
+    if scale_heads:
+        pol.views["action_net.weight"].mul_(30.0)
+    return pol
+
+
+@pytest.mark.parametrize("n,stride", [(4096, 56), (4096, 64), (100, 56), (8192, 64), (12000, 64)])
+def test_mlp_forward_vs_torch(n, stride):
+    pol = _policy()
+    k = MlpKernels(256, DEV, max_batch=16384)
+    k.pack(pol.flat)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    obs = torch.rand((n, stride), device=DEV, generator=g) * 2 - 1
+    if stride == 64:
+        obs[:, 56:] = 0
+    noise = torch.randn((n, 7), device=DEV, generator=g)
+    mean = torch.empty((n, 7), device=DEV)
+    value = torch.empty(n, device=DEV)
+    action = torch.empty((n, 7), device=DEV)
+    clipped = torch.empty((n, 7), device=DEV)
+    logp = torch.empty(n, device=DEV)
+    k.forward(obs, noise=noise, mean=mean, value=value, action=action, clipped=clipped, log_prob=logp)
+    ref_mean, ref_value = P.mlp_forward(pol.views, obs[:, :56].contiguous())
+    assert torch.allclose(mean, ref_mean, rtol=1e-4, atol=2e-5), (mean - ref_mean).abs().max()
+    assert torch.allclose(value, ref_value, rtol=1e-4, atol=2e-5), (value - ref_value).abs().max()
+    ref_action = ref_mean + torch.exp(pol.views["log_std"]) * noise
+    assert torch.allclose(action, ref_action, rtol=1e-4, atol=5e-5)
+    assert torch.allclose(clipped, ref_action.clamp(-1, 1), rtol=1e-4, atol=5e-5)
+    ref_logp = P.gaussian_log_prob(ref_action, ref_mean, pol.views["log_std"])
+    assert torch.allclose(logp, ref_logp, rtol=1e-4, atol=1e-4)
+    k.close()
+
+
+@pytest.mark.parametrize("n,total,gather", [(8192, 20000, True), (4096, 4096, False), (1000, 5000, True), (16384, 40000, True)])
+def test_mlp_loss_grad_vs_torch_autograd(n, total, gather):
+    pol = _policy(scale_heads=False)
+    k = MlpKernels(256, DEV, max_batch=16384)
+    k.pack(pol.flat)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    obs = torch.zeros((total, 64), device=DEV)
+    obs[:, :56] = torch.rand((total, 56), device=DEV, generator=g) * 2 - 1
+    with torch.no_grad():
+        m0, v0 = P.mlp_forward(pol.views, obs[:, :56].contiguous())
+    act = m0 + torch.exp(pol.views["log_std"]) * torch.randn((total, 7), device=DEV, generator=g)
+    # old log-probs from a slightly different policy so ratios spread around 1 and both clip branches occur
+    old_logp = P.gaussian_log_prob(act, m0 + 0.05 * torch.randn((total, 7), device=DEV, generator=g), pol.views["log_std"])
+    adv = torch.randn(total, device=DEV, generator=g) * 3 + 0.5
+    ret = v0 + torch.randn(total, device=DEV, generator=g)
+    idx = torch.randperm(total, device=DEV, generator=g)[:n] if gather else None
+    clip, ent, vf = 0.1, 3e-4, 0.5
+    grad = torch.empty(k.num_params, device=DEV)
+    stats = torch.zeros(4, device=DEV)
+    k.loss_grad(obs, idx, n, act, old_logp, adv, ret, clip_range=clip, ent_coef=ent, vf_coef=vf, inv_count=1.0 / n, grad_out=grad, stats_out=stats)
+
+    # reference: SB3's loss with torch autograd
+    sel = idx if gather else torch.arange(n, device=DEV)
+    flat = pol.flat.detach().clone().requires_grad_(True)
+    Pv, off = {}, 0
+    for name, shape in pol.spec:
+        cnt = math.prod(shape)
+        Pv[name] = flat[off:off + cnt].view(shape)
+        off += cnt
+    mean, value = P.mlp_forward(Pv, obs[sel, :56])
+    logp = P.gaussian_log_prob(act[sel], mean, Pv["log_std"])
+    a = adv[sel]
+    a = (a - a.mean()) / (a.std() + 1e-8)
+    ratio = torch.exp(logp - old_logp[sel])
+    pl = -torch.min(a * ratio, a * torch.clamp(ratio, 1 - clip, 1 + clip)).mean()
+    vl = torch.nn.functional.mse_loss(ret[sel], value)
+    entropy = (0.5 + 0.5 * math.log(2 * math.pi) + Pv["log_std"]).sum()
+    loss = pl + ent * (-entropy) + vf * vl
+    (ref,) = torch.autograd.grad(loss, flat)
+    frac_clipped = ((ratio - 1).abs() > clip).float().mean().item()
+    assert 0.02 < frac_clipped < 0.98          # both branches of the surrogate are exercised
+    off = 0
+    for name, shape in pol.spec:
+        cnt = math.prod(shape)
+        gk, gr = grad[off:off + cnt], ref[off:off + cnt]
+        scale = gr.abs().max().item() + 1e-12
+        err = (gk - gr).abs().max().item()
+        assert err <= 2e-4 * scale + 1e-7, f"{name}: err {err} scale {scale}"
+        off += cnt
+    assert abs(stats[0].item() - pl.item()) <= 1e-4 * (abs(pl.item()) + 1)
+    assert abs(stats[1].item() - vl.item()) <= 1e-4 * (abs(vl.item()) + 1)
+    assert abs(stats[2].item() - entropy.item()) <= 1e-5
+    k.close()
+
+
+def test_adam_step_vs_torch():
+    pol = _policy()
+    k = MlpKernels(256, DEV)
+    n = k.num_params
+    g = torch.Generator(device=DEV).manual_seed(5)
+    params = pol.flat.clone()
+    ref_p = torch.nn.Parameter(pol.flat.clone())
+    opt = torch.optim.Adam([ref_p], lr=6e-6, eps=1e-5)
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    for step in range(1, 6):
+        grad = torch.randn(n, device=DEV, generator=g) * (0.01 if step % 2 else 1e-4)  # with and without clipping
+        ref_p.grad = grad.clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 0.5)
+        opt.step()
+        k.adam_step(params, grad, m, v, lr=6e-6, eps=1e-5, max_grad_norm=0.5, step=step)
+        assert torch.allclose(params, ref_p.data, rtol=0, atol=2e-9), (params - ref_p.data).abs().max()
+    # the kernel-format weights follow the flat vector: forward uses the updated parameters
+    pol.flat.copy_(params)
+    obs = torch.rand((256, 56), device=DEV, generator=g)
+    mean, value = k.mean_value(obs)
+    rm, rv = P.mlp_forward(pol.views, obs)
+    assert torch.allclose(mean, rm, rtol=1e-4, atol=2e-5) and torch.allclose(value, rv, rtol=1e-4, atol=2e-5)
+    k.close()
+
+
+def test_gae_scan_vs_sb3_formula():
+    import ctypes as C
+    from rl_brain_trainer_amd import native
+
+    T, N = 96, 1000
+    g = torch.Generator(device=DEV).manual_seed(2)
+    rew = torch.randn((T, N), device=DEV, generator=g)
+    val = torch.randn((T, N), device=DEV, generator=g)
+    done = (torch.rand((T, N), device=DEV, generator=g) < 0.05).to(torch.uint8) * 2
+    done[10] |= 1
+    last = torch.randn(N, device=DEV, generator=g)
+    adv = torch.empty((T, N), device=DEV)
+    ret = torch.empty((T, N), device=DEV)
+    L = native.load()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    native.check(L.kp1_gae_scan(0, p(rew), p(val), p(done), p(last), 0.995, 0.95, p(adv), p(ret), T, N, None))
+    # SB3 RolloutBuffer.compute_returns_and_advantage in numpy
+    r, v, d, lv = rew.cpu().numpy(), val.cpu().numpy(), (done.cpu().numpy() & 3) != 0, last.cpu().numpy()
+    ref = np.zeros((T, N), dtype=np.float32)
+    lg = np.zeros(N, dtype=np.float32)
+    for t in reversed(range(T)):
+        nv = lv if t == T - 1 else v[t + 1]
+        nonterm = 1.0 - d[t].astype(np.float32)
+        delta = r[t] + np.float32(0.995) * nv * nonterm - v[t]
+        lg = delta + np.float32(0.995 * 0.95) * nonterm * lg
+        ref[t] = lg
+    assert np.allclose(adv.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    assert np.allclose(ret.cpu().numpy(), ref + v, rtol=1e-5, atol=1e-5)
+
+
+def test_device_curriculum_matches_golden_tracker():
+    import json
+    from conftest import GOLDEN
+
+    cases = json.loads((GOLDEN / "curriculum_tracker.json").read_text())["cases"]
+    for case in cases:
+        cur = PointCurriculum(success_rate_threshold=case["threshold"], window_episodes=case["window"],
+                              min_episodes_per_stage=case["min_episodes"], max_stage_index=case["n_stages"] - 1, device=0)
+        seq = np.array(case["successes"], dtype=np.uint8)
+        # feed in VecEnv-sized slices with idle envs in between (done bit 2 = truncated, bit 4 = success)
+        n = 96
+        stages = []
+        for s in range(0, len(seq), 7):
+            chunk = seq[s:s + 7]
+            dones = np.zeros(n, dtype=np.uint8)
+            pos = np.sort(np.random.default_rng(s).choice(n, size=len(chunk), replace=False))
+            dones[pos] = 2 | (chunk << 2)
+            cur.observe(torch.tensor(dones, device=DEV), n)
+            stages.append(cur.read().stage_index)
+        summ = cur.summary()
+        assert [h["to_stage_index"] for h in summ["history"]] == list(range(1, len(case["promoted_at"]) + 1))
+        assert [h["trigger_success_rate"] for h in summ["history"]] == case["trigger_rates"]
+        assert summ["stage_index"] == case["stage_after"][-1]
+        # stage after each slice equals the reference tracker's stage after the last episode of that slice
+        ends = [min(s + 7, len(seq)) - 1 for s in range(0, len(seq), 7)]
+        assert stages == [case["stage_after"][e] for e in ends]
+        cur.close()
