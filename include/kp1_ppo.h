@@ -107,6 +107,14 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
 int kp1_mlp_adam_step(kp1_mlp* m, float* params, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float eps,
                       float max_grad_norm, int32_t step, void* stream);
 
+/* HIP-event timing of the three MFMA GEMM kernels at minibatch size n (for bench.py's roofline block): runs each kernel
+ * `iters` times back to back on `stream` between hipEventRecord pairs and returns the mean duration in milliseconds:
+ *   out_ms[0] gemm_nt fwd layer 2 (H x H, bias+tanh)   out_ms[1] gemm_nt bwd dZ1 (H x H, dtanh)
+ *   out_ms[2] gemm_tn dW2 (H x H, split over the batch) out_ms[3] gemm_nt fwd layer 1 (64 -> H)
+ * out_flops[k] = algorithmic FLOPs of one launch of kernel k (2*M*N*K summed over both nets). */
+int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32_t n, int32_t iters, float* out_ms, double* out_flops,
+                         void* stream);
+
 /* make kp1_step / kp1_reset write observation rows with this stride (56 default, 64 = MFMA-friendly, zero padded) */
 int kp1_set_obs_stride(kp1_env* env, int32_t stride);
 

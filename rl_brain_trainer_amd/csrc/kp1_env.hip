@@ -52,10 +52,15 @@ __device__ __forceinline__ void rng_store(uint64_t* __restrict__ r64, uint32_t* 
   r32[1 * n + i] = r.uinteger;
 }
 
-__device__ __forceinline__ void store_obs_row(float* __restrict__ obs, int64_t i, const float* o) {
-  float4* dst = reinterpret_cast<float4*>(obs + i * KP1_OBS_DIM);
+// one observation row = 14 float4 stores (+2 zero float4 when the row pitch is the MFMA-friendly 64)
+__device__ __forceinline__ void store_obs_row(float* __restrict__ obs, int64_t i, const float* o, int stride = KP1_OBS_DIM) {
+  float4* dst = reinterpret_cast<float4*>(obs + i * stride);
 #pragma unroll
   for (int k = 0; k < KP1_OBS_DIM / 4; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+  if (stride > KP1_OBS_DIM) {
+    dst[14] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dst[15] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 }
 
 // Sampling half of reset(): fills a ResetSample in fp64.  KP1/envs/reset_samplers.py:168-210, 426-515.
@@ -251,6 +256,7 @@ struct StepArgs {
   R* comps;              // [n_components][N] or nullptr
   int auto_reset;
   int stage_index;
+  int obs_stride;
   const int32_t* stage_ptr;  // device-resident curriculum stage (kp1_bind_stage_ptr) or nullptr
 };
 
@@ -394,7 +400,7 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
                         (success ? KP1_DONE_SUCCESS : 0) | (invalid ? KP1_DONE_INVALID : 0));
   if (done && a.auto_reset) {
     // VecEnv auto-reset: keep the finished episode's last observation + info norms, then reset in place.
-    if (a.terminal_obs) store_obs_row(a.terminal_obs, i, o);
+    if (a.terminal_obs) store_obs_row(a.terminal_obs, i, o, a.obs_stride);
     ResetOptsDev none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     int stage = a.stage_index;
     if (a.stage_ptr) stage = kp_clipi(*a.stage_ptr, 0, kp_maxi(a.smp->n_stages - 1, 0));
@@ -427,22 +433,22 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
     st.iv(I_DRIFT, i) = drift_count;
     st.iv(I_FLAGS, i) = flags;
   }
-  store_obs_row(a.obs, i, o);
+  store_obs_row(a.obs, i, o, a.obs_stride);
 }
 
 template <typename R, int MODE>
 __global__ void __launch_bounds__(256) kp1_reset_kernel(const EnvState<R> st, const DevCfg<R>* cfg, const DevSampler* smp, const kp1_handoff_state* handoff,
-                                 const uint8_t* mask, const ResetOptsDev opts, int stage_index, float* obs) {
+                                 const uint8_t* mask, const ResetOptsDev opts, int stage_index, float* obs, int obs_stride) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= st.n) return;
   if (mask && !mask[i]) return;
   float o[KP1_OBS_DIM];
   reset_env<R, MODE>(st, *cfg, *smp, handoff, opts, stage_index, i, o);
-  if (obs) store_obs_row(obs, i, o);
+  if (obs) store_obs_row(obs, i, o, obs_stride);
 }
 
 template <typename R>
-__global__ void kp1_observe_kernel(const EnvState<R> st, const DevCfg<R>* cfgp, int mode, float* obs) {
+__global__ void kp1_observe_kernel(const EnvState<R> st, const DevCfg<R>* cfgp, int mode, float* obs, int obs_stride) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= st.n) return;
   const DevCfg<R>& cfg = *cfgp;
@@ -459,7 +465,7 @@ __global__ void kp1_observe_kernel(const EnvState<R> st, const DevCfg<R>* cfgp, 
   pose_error_norms<R>(ee, goal, pe, oe, &pn, &on);
   float o[KP1_OBS_DIM];
   build_observation<R>(cfg, mode, q, dq, pa, pe, oe, st.iv(I_STEP, i), st.iv(I_DWELL, i), o);
-  store_obs_row(obs, i, o);
+  store_obs_row(obs, i, o, obs_stride);
 }
 
 // __init__: zero state, ee_pose6 = FK(0); arm_kinematic_env.py:80-100
@@ -768,6 +774,7 @@ struct kp1_env {
   int32_t n_handoff = 0;
   double* opt_scratch = nullptr;  // 4*[N][7] + [N][6] doubles for explicit reset options / set_state
   const int32_t* stage_ptr = nullptr;  // kp1_bind_stage_ptr
+  int32_t obs_stride = KP1_OBS_DIM;    // kp1_set_obs_stride
   void* comps = nullptr;          // R[64][N] when enabled
   bool comps_enabled = false;
   size_t real_size() const { return real_type == KP1_REAL_F64 ? 8 : 4; }
@@ -838,6 +845,7 @@ int launch_step(kp1_env* e, const void* actions, float* obs, void* reward, uint8
   a.comps = (R*)e->comps;
   a.auto_reset = auto_reset;
   a.stage_index = e->stage;
+  a.obs_stride = e->obs_stride;
   a.stage_ptr = e->cfg.curriculum_enabled ? e->stage_ptr : nullptr;
   const int block = block_for(e->n);
   const dim3 grid((unsigned)((e->n + block - 1) / block));
@@ -859,10 +867,10 @@ int launch_reset(kp1_env* e, const uint8_t* mask, const ResetOptsDev& opts, int 
   const dim3 grid((unsigned)((e->n + block - 1) / block));
   if (mode == KP1_MODE_DOCK)
     hipLaunchKernelGGL((kp1_reset_kernel<R, KP1_MODE_DOCK>), grid, dim3(block), 0, e->stream, state_of<R>(e),
-                       (const DevCfg<R>*)e->dev_cfg, e->dev_smp, e->dev_handoff, mask, opts, e->stage, obs);
+                       (const DevCfg<R>*)e->dev_cfg, e->dev_smp, e->dev_handoff, mask, opts, e->stage, obs, e->obs_stride);
   else
     hipLaunchKernelGGL((kp1_reset_kernel<R, KP1_MODE_APPROACH>), grid, dim3(block), 0, e->stream, state_of<R>(e),
-                       (const DevCfg<R>*)e->dev_cfg, e->dev_smp, e->dev_handoff, mask, opts, e->stage, obs);
+                       (const DevCfg<R>*)e->dev_cfg, e->dev_smp, e->dev_handoff, mask, opts, e->stage, obs, e->obs_stride);
   HIP_TRY(hipGetLastError());
   return KP1_OK;
 }
@@ -975,6 +983,12 @@ int kp1_bind_stage_ptr(kp1_env* e, const int32_t* stage_dev) {
   e->stage_ptr = stage_dev;
   return KP1_OK;
 }
+int kp1_set_obs_stride(kp1_env* e, int32_t stride) {
+  if (!e) return fail(KP1_ERR_INVALID, "env is NULL");
+  if (stride != KP1_OBS_DIM && stride != 64) return fail(KP1_ERR_INVALID, "obs stride must be 56 or 64");
+  e->obs_stride = stride;
+  return KP1_OK;
+}
 int kp1_get_stage(const kp1_env* e, int32_t* stage_index) {
   if (!e || !stage_index) return fail(KP1_ERR_INVALID, "NULL argument");
   *stage_index = e->stage;
@@ -1061,9 +1075,9 @@ int kp1_observe(kp1_env* e, float* obs_dev) {
   const int block = block_for(e->n);
   const dim3 grid((unsigned)((e->n + block - 1) / block));
   if (e->real_type == KP1_REAL_F64)
-    hipLaunchKernelGGL(kp1_observe_kernel<double>, grid, dim3(block), 0, e->stream, state_of<double>(e), (const DevCfg<double>*)e->dev_cfg, e->mode, obs_dev);
+    hipLaunchKernelGGL(kp1_observe_kernel<double>, grid, dim3(block), 0, e->stream, state_of<double>(e), (const DevCfg<double>*)e->dev_cfg, e->mode, obs_dev, e->obs_stride);
   else
-    hipLaunchKernelGGL(kp1_observe_kernel<float>, grid, dim3(block), 0, e->stream, state_of<float>(e), (const DevCfg<float>*)e->dev_cfg, e->mode, obs_dev);
+    hipLaunchKernelGGL(kp1_observe_kernel<float>, grid, dim3(block), 0, e->stream, state_of<float>(e), (const DevCfg<float>*)e->dev_cfg, e->mode, obs_dev, e->obs_stride);
   HIP_TRY(hipGetLastError());
   return KP1_OK;
 }

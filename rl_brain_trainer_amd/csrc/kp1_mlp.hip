@@ -831,6 +831,72 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   return KP1_OK;
 }
 
+int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32_t n, int32_t iters, float* out_ms, double* out_flops,
+                         void* stream_) {
+  if (!m || !obs || !out_ms || !out_flops || iters <= 0) return fail(KP1_ERR_INVALID, "bad argument to kp1_mlp_time_kernels");
+  if (n <= 0 || n > m->max_batch) return fail(KP1_ERR_INVALID, "n exceeds the workspace max_batch");
+  int rc = mlp_check_device(m);
+  if (rc != KP1_OK) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int Hp = m->Hp;
+  const int64_t act_stride = (int64_t)m->max_batch * Hp;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  rc = launch_forward_layers(m, obs, obs_stride, nullptr, n, stream);  // fills h1/h2 with real activations
+  if (rc != KP1_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(m->dz2, m->h2, sizeof(float) * 2 * (size_t)act_stride, hipMemcpyDeviceToDevice, stream));
+  const bool small = n <= 8192;
+  auto time_it = [&](int which) -> int {
+    HIP_TRY(hipEventRecord(e0, stream));
+    for (int it = 0; it < iters; ++it) {
+      GemmNT g{};
+      g.gather = nullptr; g.ldc = Hp; g.strideC = act_stride; g.M = n; g.N = Hp;
+      if (which == 0) {
+        g.A = m->h1; g.lda = Hp; g.strideA = act_stride; g.W = m->k.w2; g.strideW = (int64_t)Hp * Hp; g.bias = m->k.b2; g.strideBias = Hp;
+        g.C = m->h2; g.K = Hp; g.Kreal = Hp;
+        if (small) hipLaunchKernelGGL((gemm_nt_kernel<64, EPI_BIAS_TANH>), dim3((n + 63) / 64, Hp / BN, 2), dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_nt_kernel<128, EPI_BIAS_TANH>), dim3((n + 127) / 128, Hp / BN, 2), dim3(256), 0, stream, g);
+      } else if (which == 1) {
+        g.A = m->dz2; g.lda = Hp; g.strideA = act_stride; g.W = m->k.w2t; g.strideW = (int64_t)Hp * Hp; g.C = m->dz1; g.aux = m->h1;
+        g.strideAux = act_stride; g.K = Hp; g.Kreal = Hp;
+        if (small) hipLaunchKernelGGL((gemm_nt_kernel<64, EPI_DTANH>), dim3((n + 63) / 64, Hp / BN, 2), dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_nt_kernel<128, EPI_DTANH>), dim3((n + 127) / 128, Hp / BN, 2), dim3(256), 0, stream, g);
+      } else if (which == 2) {
+        GemmTN t{};
+        t.B = n; t.chunk = n >= 4096 ? 512 : 256;
+        t.D = m->dz2; t.ldd = Hp; t.strideD = act_stride; t.X = m->h1; t.ldx = Hp; t.strideX = act_stride;
+        t.G = m->dz1; t.ldg = Hp; t.strideG = act_stride;  // scratch target (dz1 is rewritten by kernel 1 anyway)
+        t.Mreal = Hp; t.Nreal = Hp; t.Nload = Hp; t.n_i_tiles = Hp / 128;
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3((n + t.chunk - 1) / t.chunk, (Hp / 128) * t.n_i_tiles, 2), dim3(256), 0, stream, t);
+      } else {
+        g.A = obs; g.lda = obs_stride; g.strideA = 0; g.W = m->k.w1p; g.strideW = (int64_t)Hp * INP; g.bias = m->k.b1; g.strideBias = Hp;
+        g.C = m->h1; g.K = INP; g.Kreal = obs_stride >= INP ? INP : IN;
+        if (small) hipLaunchKernelGGL((gemm_nt_kernel<64, EPI_BIAS_TANH>), dim3((n + 63) / 64, Hp / BN, 2), dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_nt_kernel<128, EPI_BIAS_TANH>), dim3((n + 127) / 128, Hp / BN, 2), dim3(256), 0, stream, g);
+      }
+    }
+    HIP_TRY(hipEventRecord(e1, stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    out_ms[which] = ms / iters;
+    return KP1_OK;
+  };
+  for (int which : {3, 0, 1, 2}) {  // layer 1 first so h1 stays a valid activation for the others
+    rc = time_it(which);
+    if (rc != KP1_OK) return rc;
+  }
+  const double M = n, H = Hp;
+  out_flops[0] = 2.0 * 2.0 * M * H * H;
+  out_flops[1] = 2.0 * 2.0 * M * H * H;
+  out_flops[2] = 2.0 * 2.0 * M * H * H;
+  out_flops[3] = 2.0 * 2.0 * M * H * INP;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return KP1_OK;
+}
+
 int kp1_mlp_adam_step(kp1_mlp* m, float* params, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float eps, float max_grad_norm,
                       int32_t step, void* stream_) {
   if (!m || !params || !grad || !exp_avg || !exp_avg_sq || step <= 0) return fail(KP1_ERR_INVALID, "bad argument to kp1_mlp_adam_step");

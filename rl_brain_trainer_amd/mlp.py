@@ -27,6 +27,7 @@ class MlpKernels:
         L.kp1_mlp_forward.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.kp1_mlp_loss_grad.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, f32, f32, vp, f32, f32, f32, f32, vp, vp, vp]
         L.kp1_mlp_adam_step.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, i32, vp]
+        L.kp1_mlp_time_kernels.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
         self.hidden = hidden
         self.device = device
         self.max_batch = int(max_batch)
@@ -71,3 +72,11 @@ class MlpKernels:
 
     def adam_step(self, params, grad, exp_avg, exp_avg_sq, *, lr: float, eps: float, max_grad_norm: float, step: int) -> None:
         native.check(self.L.kp1_mlp_adam_step(self._h, _p(params), _p(grad), _p(exp_avg), _p(exp_avg_sq), lr, eps, max_grad_norm, step, self._stream()))
+
+    def time_kernels(self, obs: torch.Tensor, n: int, iters: int = 20) -> dict[str, dict[str, float]]:
+        """HIP-event timings of the MFMA GEMM kernels at minibatch size n (bench.py roofline block)."""
+        ms = (C.c_float * 4)()
+        fl = (C.c_double * 4)()
+        native.check(self.L.kp1_mlp_time_kernels(self._h, _p(obs), obs.shape[-1], n, iters, C.cast(ms, C.c_void_p), C.cast(fl, C.c_void_p), self._stream()))
+        names = ("gemm_nt_fwd_l2", "gemm_nt_bwd_dz1", "gemm_tn_dw2", "gemm_nt_fwd_l1")
+        return {nm: {"ms": float(ms[i]), "flops": float(fl[i]), "tflops": float(fl[i]) / (float(ms[i]) * 1e-3) / 1e12} for i, nm in enumerate(names)}

@@ -89,6 +89,7 @@ def load() -> C.CDLL:
     L.kp1_curriculum_observe.argtypes = [i32, vp, vp, i32, i32, vp]
     L.kp1_curriculum_read.argtypes = [i32, vp, vp, vp]
     L.kp1_bind_stage_ptr.argtypes = [vp, vp]
+    L.kp1_set_obs_stride.argtypes = [vp, i32]
     if L.kp1_config_size() != C.sizeof(kcfg.Kp1Config):
         raise Kp1Error(f"kp1_config layout mismatch: library {L.kp1_config_size()} vs binding {C.sizeof(kcfg.Kp1Config)}")
     _lib = L

@@ -190,8 +190,12 @@ class PPO:
             curriculum.attach(env)
         T, N = cfg.n_steps, self.n_envs
         dev = self.device
-        self.obs_buf = torch.zeros((T + 1, N, OBS_DIM), dtype=torch.float32, device=dev)
-        self.term_obs_buf = torch.zeros((T, N, OBS_DIM), dtype=torch.float32, device=dev)
+        # hip backend: observation rows are written with pitch 64 (zero padded) so the MFMA GEMMs read them directly
+        self.obs_w = 64 if backend == "hip" else OBS_DIM
+        if backend == "hip":
+            env.set_obs_stride(64)
+        self.obs_buf = torch.zeros((T + 1, N, self.obs_w), dtype=torch.float32, device=dev)
+        self.term_obs_buf = torch.zeros((T, N, self.obs_w), dtype=torch.float32, device=dev)
         self.act_buf = torch.zeros((T, N, ACT_DIM), dtype=torch.float32, device=dev)
         self.clip_act = torch.zeros((N, ACT_DIM), dtype=torch.float32, device=dev)
         self.logp_buf = torch.zeros((T, N), dtype=torch.float32, device=dev)
@@ -210,13 +214,21 @@ class PPO:
         if backend == "hip":
             from . import mlp as _mlp
 
-            self._mlp = _mlp.MlpKernels(cfg.hidden, self.device)
+            local_bs = max(cfg.batch_size // self.dist.world_size, 1)
+            self._mlp = _mlp.MlpKernels(cfg.hidden, self.device, max_batch=max(N, local_bs, 8192))
+            self._mlp.pack(self.policy.flat)
+            self.grad = torch.zeros_like(self.policy.flat)
+            self.stats_dev = torch.zeros(4, dtype=torch.float32, device=dev)
+            self.noise = torch.zeros((N, ACT_DIM), dtype=torch.float32, device=dev)
+        elif backend != "torch":
+            raise ValueError("backend must be 'hip' or 'torch'")
 
     # ------------------------------------------------------------------ policy evaluation
     def _forward(self, obs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        """mean[n,7], value[n] for obs [n, 56 or 64]"""
         if self._mlp is not None:
-            return self._mlp.forward(self.policy, obs)
-        return mlp_forward(self.policy.views, obs)
+            return self._mlp.mean_value(obs.contiguous())
+        return mlp_forward(self.policy.views, obs[:, :OBS_DIM])
 
     def predict(self, obs: torch.Tensor, deterministic: bool = True) -> torch.Tensor:
         """model.predict(obs, deterministic): mean (or a sample) clipped to the action space (eval_three_stage.py:25-27)."""
@@ -244,20 +256,26 @@ class PPO:
         std = torch.exp(log_std)
         world = self.dist.world_size
         for t in range(T):
-            mean, value = self._forward(self.obs_buf[t])
-            noise = torch.randn((N, ACT_DIM), dtype=torch.float32, device=self.device, generator=self.gen)
-            action = torch.addcmul(mean, std, noise)
-            self.act_buf[t].copy_(action)
-            self.logp_buf[t].copy_((-0.5 * noise * noise - log_std - LOG_SQRT_2PI).sum(-1))
-            self.val_buf[t].copy_(value)
-            torch.clamp(action, -1.0, 1.0, out=self.clip_act)
+            if self._mlp is not None:
+                # 3 launches: two MFMA layer GEMMs + the head kernel (heads, sampling, log-prob, clip fused)
+                self.noise.normal_(generator=self.gen)
+                self._mlp.forward(self.obs_buf[t], noise=self.noise, value=self.val_buf[t], action=self.act_buf[t],
+                                  clipped=self.clip_act, log_prob=self.logp_buf[t])
+            else:
+                mean, value = self._forward(self.obs_buf[t])
+                noise = torch.randn((N, ACT_DIM), dtype=torch.float32, device=self.device, generator=self.gen)
+                action = torch.addcmul(mean, std, noise)
+                self.act_buf[t].copy_(action)
+                self.logp_buf[t].copy_((-0.5 * noise * noise - log_std - LOG_SQRT_2PI).sum(-1))
+                self.val_buf[t].copy_(value)
+                torch.clamp(action, -1.0, 1.0, out=self.clip_act)
             env.step_into(self.clip_act, self.obs_buf[t + 1], self.rew_buf[t], self.done_buf[t], self.term_obs_buf[t], True)
             if self.curriculum is not None:
                 dones = self.dist.all_gather_bytes(self.done_buf[t])
                 self.curriculum.observe(dones, N * world)
         self.num_timesteps += T * N * world
         # time-limit bootstrap: r += gamma * V(terminal_obs) on truncated steps (one batched critic pass, no host sync)
-        _, tv = self._forward(self.term_obs_buf.view(T * N, OBS_DIM))
+        _, tv = self._forward(self.term_obs_buf.view(T * N, self.obs_w))
         stream = torch.cuda.current_stream(self.device).cuda_stream
         dev = self.device.index or 0
         native.check(self.L.kp1_bootstrap_truncated(dev, C.c_void_p(self.rew_buf.data_ptr()), C.c_void_p(tv.data_ptr()),
@@ -273,7 +291,7 @@ class PPO:
         cfg = self.cfg
         T, N = cfg.n_steps, self.n_envs
         total = T * N
-        obs = self.obs_buf[:T].view(total, OBS_DIM)
+        obs = self.obs_buf[:T].view(total, self.obs_w)
         act = self.act_buf.view(total, ACT_DIM)
         old_logp = self.logp_buf.view(total)
         adv = self.adv_buf.view(total)
@@ -282,15 +300,42 @@ class PPO:
         local_bs = max(cfg.batch_size // world, 1)
         stats = torch.zeros(4, device=self.device)
         n_updates = 0
+        if self._mlp is not None:
+            self.stats_dev.zero_()
         for _epoch in range(cfg.n_epochs):
             perm = torch.randperm(total, device=self.device, generator=self.gen)
             for start in range(0, total, local_bs):
                 idx = perm[start:start + local_bs]
-                loss_terms = self._minibatch_step(obs[idx], act[idx], old_logp[idx], adv[idx], ret[idx])
-                stats += loss_terms
+                if self._mlp is not None:
+                    self._hip_minibatch_step(obs, idx, act, old_logp, adv, ret)
+                else:
+                    stats += self._minibatch_step(obs[idx], act[idx], old_logp[idx], adv[idx], ret[idx])
                 n_updates += 1
+        if self._mlp is not None:
+            stats = self.stats_dev.clone()
         self.last_stats = dict(zip(("policy_loss", "value_loss", "entropy", "approx_kl"), (stats / max(n_updates, 1)).tolist()))
         self.last_stats["n_updates"] = n_updates
+
+    def _hip_minibatch_step(self, obs, idx, act, old_logp, adv, ret) -> None:
+        """one optimiser step, all on the device: gathered fwd + loss + bwd (MFMA), flat grad all-reduce, clip + Adam + repack"""
+        cfg = self.cfg
+        n = int(idx.numel())
+        world = self.dist.world_size
+        adv_stats = None
+        if cfg.normalize_advantage and self.dist.enabled:
+            a = adv[idx]
+            s = torch.stack([a.sum(), (a * a).sum(), torch.tensor(float(n), device=a.device)])
+            self.dist.all_reduce_sum(s)
+            mean = s[0] / s[2]
+            var = ((s[1] - s[2] * mean * mean) / (s[2] - 1.0)).clamp_min(0)
+            adv_stats = torch.stack([mean, 1.0 / (var.sqrt() + 1e-8)]).float()
+        self._mlp.loss_grad(obs, idx, n, act, old_logp, adv, ret, clip_range=cfg.clip_range, ent_coef=cfg.ent_coef / world, vf_coef=cfg.vf_coef,
+                            inv_count=1.0 / (n * world), grad_out=self.grad, stats_out=self.stats_dev, adv_stats=adv_stats,
+                            normalize=cfg.normalize_advantage)
+        self.dist.all_reduce_sum(self.grad)
+        self.adam_t += 1
+        self._mlp.adam_step(self.policy.flat, self.grad, self.adam_m, self.adam_v, lr=cfg.learning_rate, eps=cfg.adam_eps,
+                            max_grad_norm=cfg.max_grad_norm, step=self.adam_t)
 
     def _normalize_adv(self, adv: torch.Tensor) -> torch.Tensor:
         if not self.cfg.normalize_advantage or adv.numel() * self.dist.world_size <= 1:
@@ -307,11 +352,7 @@ class PPO:
     def _minibatch_step(self, obs, act, old_logp, adv, ret) -> torch.Tensor:
         cfg = self.cfg
         adv = self._normalize_adv(adv)
-        if self._mlp is not None:
-            grad, terms = self._mlp.loss_and_grad(self.policy, obs, act, old_logp, adv, ret, cfg.clip_range, cfg.ent_coef, cfg.vf_coef,
-                                                  1.0 / (obs.shape[0] * self.dist.world_size))
-        else:
-            grad, terms = self._torch_loss_and_grad(obs, act, old_logp, adv, ret)
+        grad, terms = self._torch_loss_and_grad(obs[:, :OBS_DIM], act, old_logp, adv, ret)
         self.dist.all_reduce_sum(grad)
         self._clip_and_adam(grad)
         return terms

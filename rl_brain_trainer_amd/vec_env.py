@@ -65,6 +65,7 @@ class ArmKinematicVecEnv:
         self.reward = torch.zeros(n, dtype=self.dtype, device=self.device)
         self.done = torch.zeros(n, dtype=torch.uint8, device=self.device)
         self._mode_name = config.mode_name
+        self.obs_stride = kcfg.OBS_DIM
         self._components = False
         if reward_components:
             self.enable_reward_components(True)
@@ -124,6 +125,13 @@ class ArmKinematicVecEnv:
             if key in stage_updates:
                 setattr(c.env, key, float(stage_updates[key]))
         native.check(self.L.kp1_update_config(self._handle, C.byref(c)))
+
+    def set_obs_stride(self, stride: int) -> None:
+        """Row pitch of every observation buffer handed to reset/step (56, or 64 = zero-padded for the MFMA GEMMs)."""
+        native.check(self.L.kp1_set_obs_stride(self._handle, int(stride)))
+        self.obs_stride = int(stride)
+        self.obs = torch.zeros((self.n_envs, self.obs_stride), dtype=torch.float32, device=self.device)
+        self.terminal_obs = torch.zeros_like(self.obs)
 
     def seed(self, seed: int, first_env_id: int = 0) -> None:
         native.check(self.L.kp1_seed(self._handle, int(seed), int(first_env_id)))

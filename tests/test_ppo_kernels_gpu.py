@@ -130,7 +130,7 @@ def test_adam_step_vs_torch():
         torch.nn.utils.clip_grad_norm_([ref_p], 0.5)
         opt.step()
         k.adam_step(params, grad, m, v, lr=6e-6, eps=1e-5, max_grad_norm=0.5, step=step)
-        assert torch.allclose(params, ref_p.data, rtol=0, atol=2e-9), (params - ref_p.data).abs().max()
+        assert torch.allclose(params, ref_p.data, rtol=0, atol=6e-8), (params - ref_p.data).abs().max()  # 1 ulp at |p| ~ 0.5; the update itself is ~6e-6
     # the kernel-format weights follow the flat vector: forward uses the updated parameters
     pol.flat.copy_(params)
     obs = torch.rand((256, 56), device=DEV, generator=g)
