@@ -28,7 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int IN = KP1_MLP_IN, INP = KP1_MLP_IN_PAD, ACT = KP1_MLP_ACT, HEADS = 8;
-constexpr int BN = 128, BK = 32, LDT = BK + 4;  // LDS row pitch 36 floats: ds_read_b128 conflict-free (guide: pad by one access width)
+constexpr int BK = 32, LDT = BK + 4;  // LDS row pitch 36 floats: ds_read_b128 conflict-free (guide: pad by one access width)
 constexpr float LOG_SQRT_2PI = 0.9189385332046727f;
 
 enum { EPI_BIAS_TANH = 0, EPI_DTANH = 1 };
@@ -44,60 +44,55 @@ struct GemmNT {
   int M, N, K, Kreal;                                  // K multiple of 32; A columns >= Kreal read as 0
 };
 
-// C = epi(A W^T): block tile BM x 128, 4 waves, each wave (BM/WM) x (128/WN) with 32x32 MFMA tiles.
-template <int BM, int EPI>
+// C = epi(A W^T).  One workgroup owns 64 rows x BN columns (BN = 256: the whole hidden width, or 128 for small
+// batches) for one net.  The 64 x K block of A is loaded ONCE and stays in LDS; W streams through a double-buffered
+// [BN][32] stage, so every stage carries 4096 MFMA cycles per wave (BN = 256) against one L2 round trip, and A is
+// never re-read.  4 waves, each 64 columns wide (2 MFMA column blocks) and RB row blocks tall.
+template <int BN, int EPI>
 __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmNT g) {
-  constexpr int WM = BM == 128 ? 2 : 1, WN = 4 / WM;
-  constexpr int RB = BM / WM / 32, CB = BN / WN / 32;
-  __shared__ float lds[2 * (BM + BN) * LDT];
-  auto As = [&](int buf) { return lds + buf * (BM + BN) * LDT; };
-  auto Ws = [&](int buf) { return lds + buf * (BM + BN) * LDT + BM * LDT; };
+  constexpr int BM = 64;
+  constexpr int WN = BN / 64, WM = 4 / WN;
+  constexpr int RB = BM / WM / 32, CB = 2;
+  constexpr int W_LOADS = BN * 8 / 256;
+  extern __shared__ float lds[];
+  const int lda_s = g.K + 4;                 // LDS pitch of the resident A block (bank-conflict-free b128 reads)
+  float* As = lds;
+  float* Ws0 = lds + BM * lda_s;
+  float* Ws1 = Ws0 + BN * LDT;
 
   const int z = blockIdx.z;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const float* __restrict__ A = g.A + z * g.strideA;
-  const float* __restrict__ W = g.W + z * g.strideW;
+  const float* __restrict__ W = g.W + z * g.strideW + (int64_t)n0 * g.K;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN;
 
-  // staging map: float4 f = tid + 256*j ; row = f / 8, c4 = f % 8
-  constexpr int A_LOADS = BM * 8 / 256, W_LOADS = BN * 8 / 256;
-  int64_t a_row_off[A_LOADS];
-  bool a_row_ok[A_LOADS];
+  // ---- prologue: first W stage to registers, whole A block to LDS
+  float4 rw[W_LOADS];
 #pragma unroll
-  for (int j = 0; j < A_LOADS; ++j) {
-    const int row = (tid + 256 * j) >> 3;
-    const int m = m0 + row;
-    a_row_ok[j] = m < g.M;
-    const int64_t src = a_row_ok[j] ? (g.gather ? g.gather[m] : (int64_t)m) : 0;
-    a_row_off[j] = src * g.lda;
+  for (int j = 0; j < W_LOADS; ++j) {
+    const int f = tid + 256 * j;
+    rw[j] = *reinterpret_cast<const float4*>(W + (int64_t)(f >> 3) * g.K + 4 * (f & 7));
   }
-  float4 ra[A_LOADS], rw[W_LOADS];
-  auto load_tile = [&](int k0) {
-#pragma unroll
-    for (int j = 0; j < A_LOADS; ++j) {
-      const int c4 = (tid + 256 * j) & 7;
-      const int k = k0 + 4 * c4;
-      ra[j] = (a_row_ok[j] && k < g.Kreal) ? *reinterpret_cast<const float4*>(A + a_row_off[j] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const int kq = g.K >> 2;                 // float4 per A row
+    for (int f = tid; f < BM * kq; f += 256) {
+      const int row = f / kq, c4 = f - row * kq;
+      const int m = m0 + row, k = 4 * c4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < g.M && k < g.Kreal) {
+        const int64_t src = g.gather ? g.gather[m] : (int64_t)m;
+        v = *reinterpret_cast<const float4*>(A + src * g.lda + k);
+      }
+      *reinterpret_cast<float4*>(As + row * lda_s + k) = v;
     }
+  }
 #pragma unroll
-    for (int j = 0; j < W_LOADS; ++j) {
-      const int f = tid + 256 * j, row = f >> 3, c4 = f & 7;
-      rw[j] = *reinterpret_cast<const float4*>(W + (int64_t)(n0 + row) * g.K + k0 + 4 * c4);
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < A_LOADS; ++j) {
-      const int f = tid + 256 * j, row = f >> 3, c4 = f & 7;
-      *reinterpret_cast<float4*>(As(buf) + row * LDT + 4 * c4) = ra[j];
-    }
-#pragma unroll
-    for (int j = 0; j < W_LOADS; ++j) {
-      const int f = tid + 256 * j, row = f >> 3, c4 = f & 7;
-      *reinterpret_cast<float4*>(Ws(buf) + row * LDT + 4 * c4) = rw[j];
-    }
-  };
+  for (int j = 0; j < W_LOADS; ++j) {
+    const int f = tid + 256 * j;
+    *reinterpret_cast<float4*>(Ws0 + (f >> 3) * LDT + 4 * (f & 7)) = rw[j];
+  }
+  __syncthreads();
 
   f32x16 acc[RB][CB];
 #pragma unroll
@@ -108,19 +103,26 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmNT g) {
       for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
 
   const int KT = g.K / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
+  const float* as_base = As + (wr * (BM / WM) + (lane & 31)) * lda_s + 4 * (lane >> 5);
   for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < KT) load_tile((kt + 1) * BK);
-    const float* as = As(buf) + (wr * (BM / WM) + (lane & 31)) * LDT + 4 * (lane >> 5);
-    const float* ws = Ws(buf) + (wc * (BN / WN) + (lane & 31)) * LDT + 4 * (lane >> 5);
+    const float* ws_cur = (kt & 1) ? Ws1 : Ws0;
+    float* ws_nxt = (kt & 1) ? Ws0 : Ws1;
+    // unconditional prefetch (the last iteration re-reads its own stage): keeping the loads and the LDS stores out of
+    // conditional blocks lets hipcc hold rw[] in registers; inside `if`s it spills the array to scratch and waits
+    // for the loads before the MFMAs, which destroys the overlap
+    const int k_next = (kt + 1 < KT ? kt + 1 : kt) * BK;
+#pragma unroll
+    for (int j = 0; j < W_LOADS; ++j) {
+      const int f = tid + 256 * j;
+      rw[j] = *reinterpret_cast<const float4*>(W + (int64_t)(f >> 3) * g.K + k_next + 4 * (f & 7));
+    }
+    const float* as = as_base + kt * BK;
+    const float* ws = ws_cur + (wc * 64 + (lane & 31)) * LDT + 4 * (lane >> 5);
 #pragma unroll
     for (int kg = 0; kg < BK / 8; ++kg) {
       float4 a[RB], b[CB];
 #pragma unroll
-      for (int r = 0; r < RB; ++r) a[r] = *reinterpret_cast<const float4*>(as + r * 32 * LDT + kg * 8);
+      for (int r = 0; r < RB; ++r) a[r] = *reinterpret_cast<const float4*>(as + r * 32 * lda_s + kg * 8);
 #pragma unroll
       for (int c = 0; c < CB; ++c) b[c] = *reinterpret_cast<const float4*>(ws + c * 32 * LDT + kg * 8);
 #pragma unroll
@@ -133,39 +135,71 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmNT g) {
           acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].w, b[c].w, acc[r][c], 0, 0, 0);
         }
     }
-    if (kt + 1 < KT) store_tile(buf ^ 1);
+#pragma unroll
+    for (int j = 0; j < W_LOADS; ++j) {
+      const int f = tid + 256 * j;
+      *reinterpret_cast<float4*>(ws_nxt + (f >> 3) * LDT + 4 * (f & 7)) = rw[j];
+    }
     __syncthreads();
   }
 
+  // Epilogue in three passes so no memory operation is pending while tanhf's divergent blocks run: (1) issue every
+  // load, (2) compute in registers, (3) issue every store.  (Interleaving them makes hipcc place s_waitcnt vmcnt(0)
+  // in each conditional block, which serialises the stores: 32 dependent store round trips per lane.)
   float* __restrict__ C = g.C + z * g.strideC;
+  const int mbase = m0 + wr * (BM / WM) + 4 * (lane >> 5);
+  float bias[CB];
+  float hval[EPI == EPI_DTANH ? CB : 1][RB][16];
 #pragma unroll
   for (int c = 0; c < CB; ++c) {
-    const int n = n0 + wc * (BN / WN) + c * 32 + (lane & 31);
-    float bias = 0.f, csum = 0.f;
-    if constexpr (EPI == EPI_BIAS_TANH) bias = g.bias[z * g.strideBias + n];
+    const int n = n0 + wc * 64 + c * 32 + (lane & 31);
+    if constexpr (EPI == EPI_BIAS_TANH) bias[c] = g.bias[z * g.strideBias + n];
+    else {
+      bias[c] = 0.f;
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = mbase + r * 32 + (e & 3) + 8 * (e >> 2);
+          hval[c][r][e] = m < g.M ? g.aux[z * g.strideAux + (int64_t)m * g.ldc + n] : 0.f;
+        }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CB; ++c) {
+    float csum = 0.f;
 #pragma unroll
     for (int r = 0; r < RB; ++r)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wr * (BM / WM) + r * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (m < g.M) {
-          float v = acc[r][c][e];
-          if constexpr (EPI == EPI_BIAS_TANH) {
-            v = tanhf(v + bias);
-          } else {
-            const float h = g.aux[z * g.strideAux + (int64_t)m * g.ldc + n];
-            v = v * (1.f - h * h);
-            csum += v;
-          }
-          C[(int64_t)m * g.ldc + n] = v;
+        float v = acc[r][c][e];
+        if constexpr (EPI == EPI_BIAS_TANH) {
+          v = tanhf(v + bias[c]);
+        } else {
+          const float h = hval[c][r][e];
+          v = v * (1.f - h * h);
+          csum += v;  // rows >= M carry zero accumulators (their A rows were loaded as 0)
         }
+        acc[r][c][e] = v;
       }
     if constexpr (EPI == EPI_DTANH) {
       if (g.colsum) {
+        const int n = n0 + wc * 64 + c * 32 + (lane & 31);
         csum += __shfl_xor(csum, 32);
         if (lane < 32) atomicAdd(g.colsum + z * g.strideColsum + n, csum);
       }
     }
+  }
+#pragma unroll
+  for (int c = 0; c < CB; ++c) {
+    const int n = n0 + wc * 64 + c * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = mbase + r * 32 + (e & 3) + 8 * (e >> 2);
+        if (m < g.M) C[(int64_t)m * g.ldc + n] = acc[r][c][e];
+      }
   }
 }
 
@@ -179,94 +213,98 @@ struct GemmTN {
   int n_i_tiles;
 };
 
-// dW[o][i] += sum_b D[b][o] X[b][i].  Block tile 128(o) x 128(i), 4 waves 2x2, wave tile 64x64 with the row/col
-// blocks interleaved (o = base + 2*(l&31) + rb) so one ds_read_b64 per operand feeds two MFMA row (col) blocks.
+// dW[o][i] += sum_b D[b][o] X[b][i].  Block tile 64(o) x 64(i), 4 waves 2x2, one 32x32 MFMA tile per wave.
+// Both operands are K(b)-major in LDS exactly as they sit in memory (rows of dZ / H), so lane l reads
+// D[b = 2s + (l>>5)][o = wr*32 + (l&31)] and X[b][i = wc*32 + (l&31)]: conflict-free ds_read_b32, no transposes.
+// Stages are 128 batch rows deep (4096 MFMA cycles per wave per stage, double buffered) so the next stage's loads
+// are covered.  Small tiles + long batch chunks keep 256 workgroups busy while the split-K atomic traffic stays at
+// n_chunks * H*H*4 B (4 MB at B = 8192, H = 256) instead of 16.8 MB with 128x128 tiles.
 // grid: x = B chunk, y = o_tile * n_i_tiles + i_tile, z = net.
+template <bool GATHER>
 __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmTN g) {
-  constexpr int TB = 32, LDW = 128 + 4;
-  __shared__ float lds[2 * 2 * TB * LDW];
-  auto Ds = [&](int buf) { return lds + buf * 2 * TB * LDW; };
-  auto Xs = [&](int buf) { return lds + buf * 2 * TB * LDW + TB * LDW; };
+  constexpr int TB = 128, TT = 64, LDW = TT + 4, LOADS = TB * TT / 4 / 256;  // 8 float4 per thread per operand
+  extern __shared__ float lds[];
   const int z = blockIdx.z;
-  const int o0 = (blockIdx.y / g.n_i_tiles) * 128, i0 = (blockIdx.y % g.n_i_tiles) * 128;
+  const int o0 = (blockIdx.y / g.n_i_tiles) * TT, i0 = (blockIdx.y % g.n_i_tiles) * TT;
   const int b_begin = blockIdx.x * g.chunk;
   const int b_end = min(b_begin + g.chunk, g.B);
-  const float* __restrict__ D = g.D + z * g.strideD;
+  const float* __restrict__ D = g.D + z * g.strideD + o0;
   const float* __restrict__ X = g.X + z * g.strideX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
+  const int srow = tid >> 4, sc4 = tid & 15;  // staging: f = tid + 256*j -> row = srow + 16*j, c4 = sc4
+  // columns of X past Nload are not readable (layer 1: 56 or 64 obs columns under a 64-wide tile): clamp + zero
+  const bool x_col_ok = i0 + 4 * sc4 < g.Nload;
+  const int x_col = x_col_ok ? i0 + 4 * sc4 : 0;
+  const int b_last = b_end - 1;
 
-  // staging: tile TB x 128 floats = 1024 float4 per operand; f = tid + 256*j, row = f / 32, c4 = f % 32
-  float4 rd[4], rx[4];
-  auto load_tile = [&](int b0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int f = tid + 256 * j, row = f >> 5, c4 = f & 31;
-      const int b = b0 + row;
-      const bool ok = b < b_end;
-      rd[j] = ok ? *reinterpret_cast<const float4*>(D + (int64_t)b * g.ldd + o0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const int col = i0 + 4 * c4;
-      if (ok && col < g.Nload) {
-        const int64_t src = g.gatherX ? g.gatherX[b] : (int64_t)b;
-        rx[j] = *reinterpret_cast<const float4*>(X + src * g.ldx + col);
-      } else {
-        rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int f = tid + 256 * j, row = f >> 5, c4 = f & 31;
-      *reinterpret_cast<float4*>(Ds(buf) + row * LDW + 4 * c4) = rd[j];
-      *reinterpret_cast<float4*>(Xs(buf) + row * LDW + 4 * c4) = rx[j];
-    }
-  };
+  // Branch-free staging: out-of-range rows are clamped to the last valid row and zeroed after the load, so all 16
+  // global loads of a stage are issued back to back (conditional blocks made hipcc wait vmcnt(0) between them).
+  float4 rd[LOADS], rx[LOADS];
+#define KP1_TN_LOAD(b0)                                                                                   \
+  {                                                                                                       \
+    int64_t xrow[LOADS];                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < LOADS; ++j) {                                                   \
+      const int b = min((b0) + srow + 16 * j, b_last);                                                    \
+      xrow[j] = GATHER ? g.gatherX[b] : (int64_t)b;                                                       \
+    }                                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < LOADS; ++j) {                                                   \
+      const int b = min((b0) + srow + 16 * j, b_last);                                                    \
+      rd[j] = *reinterpret_cast<const float4*>(D + (int64_t)b * g.ldd + 4 * sc4);                         \
+      rx[j] = *reinterpret_cast<const float4*>(X + xrow[j] * g.ldx + x_col);                              \
+    }                                                                                                     \
+  }
+  // the zeroing of clamped rows happens here, at LDS-store time, so nothing touches the loaded registers (and no
+  // vmcnt wait is needed) until the MFMAs of the current stage have been issued
+#define KP1_TN_STORE(buf, b0)                                                                             \
+  _Pragma("unroll") for (int j = 0; j < LOADS; ++j) {                                                     \
+    const float keep = ((b0) + srow + 16 * j <= b_last) ? 1.f : 0.f;                                      \
+    const float keepx = x_col_ok ? keep : 0.f;                                                            \
+    float* base = lds + (buf) * 2 * TB * LDW + (srow + 16 * j) * LDW + 4 * sc4;                           \
+    *reinterpret_cast<float4*>(base) = make_float4(rd[j].x * keep, rd[j].y * keep, rd[j].z * keep, rd[j].w * keep);          \
+    *reinterpret_cast<float4*>(base + TB * LDW) = make_float4(rx[j].x * keepx, rx[j].y * keepx, rx[j].z * keepx, rx[j].w * keepx); \
+  }
 
-  f32x16 acc[2][2];
+  f32x16 acc;
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 
   const int KT = (b_end - b_begin + TB - 1) / TB;
-  if (KT > 0) {
-    load_tile(b_begin);
-    store_tile(0);
-  }
+  if (KT <= 0) return;  // whole workgroup (uniform): nothing to reduce
+  KP1_TN_LOAD(b_begin)
+  KP1_TN_STORE(0, b_begin)
   __syncthreads();
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < KT) load_tile(b_begin + (kt + 1) * TB);
-    const float* ds = Ds(buf) + (lane >> 5) * LDW + wr * 64 + 2 * (lane & 31);
-    const float* xs = Xs(buf) + (lane >> 5) * LDW + wc * 64 + 2 * (lane & 31);
+    KP1_TN_LOAD(b_begin + (kt + 1) * TB)  // past the chunk end: clamped rows, zeroed
+    const float* ds = lds + buf * 2 * TB * LDW + (lane >> 5) * LDW + wr * 32 + (lane & 31);
+    const float* xs = ds + TB * LDW + (wc - wr) * 32;
 #pragma unroll
-    for (int s = 0; s < TB / 2; ++s) {
-      const float2 a = *reinterpret_cast<const float2*>(ds + 2 * s * LDW);
-      const float2 b = *reinterpret_cast<const float2*>(xs + 2 * s * LDW);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
+    for (int s0 = 0; s0 < TB / 2; s0 += 8) {
+      float av[8], xv[8];  // LDS reads of 8 steps in flight ahead of their MFMAs
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        av[u] = ds[2 * (s0 + u) * LDW];
+        xv[u] = xs[2 * (s0 + u) * LDW];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], xv[u], acc, 0, 0, 0);
+      // schedule: the 16 LDS reads of this group first, then its 8 MFMAs (otherwise hipcc waits lgkmcnt(0) per pair)
+      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
     }
-    if (kt + 1 < KT) store_tile(buf ^ 1);
+    KP1_TN_STORE(buf ^ 1, b_begin + (kt + 1) * TB)
     __syncthreads();
   }
+#undef KP1_TN_LOAD
+#undef KP1_TN_STORE
   float* __restrict__ G = g.G + z * g.strideG;
+  const int i = i0 + wc * 32 + (lane & 31);
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int i = i0 + wc * 64 + 2 * (lane & 31) + c;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row32 = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const int o = o0 + wr * 64 + 2 * row32 + r;
-        if (o < g.Mreal && i < g.Nreal) atomicAdd(G + (int64_t)o * g.ldg + i, acc[r][c][e]);
-      }
-    }
+  for (int e = 0; e < 16; ++e) {
+    const int o = o0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+    if (o < g.Mreal && i < g.Nreal) atomicAdd(G + (int64_t)o * g.ldg + i, acc[e]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- heads
@@ -374,14 +412,22 @@ __global__ void __launch_bounds__(256) head_train_kernel(const HeadArgs a) {
   float* adv_ms = red + 4;                 // [2]
   for (int k = threadIdx.x; k < HEADS * a.Hp; k += 256) w3s[k] = a.w3[k];
   if (threadIdx.x < 4) red[threadIdx.x] = 0.f;
+  // fixed-order parallel reduction of the per-block advantage partials (wave 0; a.n_adv_partials <= 128)
+  double ps = 0.0, pss = 0.0;
+  if (a.adv_mode == 1 && threadIdx.x < 64) {
+    for (int k = threadIdx.x; k < a.n_adv_partials; k += 64) {
+      ps += a.adv_partials[2 * k];
+      pss += a.adv_partials[2 * k + 1];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      ps += __shfl_xor(ps, off);
+      pss += __shfl_xor(pss, off);
+    }
+  }
   if (threadIdx.x == 0) {
     float mean = 0.f, inv_std = 1.f;
     if (a.adv_mode == 1) {  // statistics of this minibatch, torch .mean() / .std() (unbiased)
-      double s = 0.0, ss = 0.0;
-      for (int k = 0; k < a.n_adv_partials; ++k) {
-        s += a.adv_partials[2 * k];
-        ss += a.adv_partials[2 * k + 1];
-      }
+      const double s = ps, ss = pss;
       const double m = s / a.n;
       const double var = a.n > 1 ? fmax((ss - a.n * m * m) / (a.n - 1), 0.0) : 0.0;
       mean = (float)m;
@@ -607,9 +653,12 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
                                                    int64_t n, const double* __restrict__ partials, int n_partials, float lr, float eps, float max_norm,
                                                    float bc1, float bc2_sqrt) {
   __shared__ float scale_s;
+  double s = 0.0;
+  if (threadIdx.x < 64) {
+    for (int k = threadIdx.x; k < n_partials; k += 64) s += partials[k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  }
   if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int k = 0; k < n_partials; ++k) s += partials[k];
     const float norm = (float)sqrt(s);
     scale_s = max_norm > 0.f ? fminf(max_norm / (norm + 1e-6f), 1.f) : 1.f;
   }
@@ -644,8 +693,50 @@ namespace {
 
 constexpr int N_PARTIALS = 128;
 
+// rows of the batch each TN workgroup reduces: aim at ~256 workgroups (one per CU) for the H x H gradient
+int tn_chunk_rows(int n, int Hp) {
+  const int tiles = (Hp / 64) * (Hp / 64) * 2;
+  int chunks = (256 + tiles - 1) / tiles;
+  if (chunks < 1) chunks = 1;
+  int rows = (n + chunks - 1) / chunks;
+  rows = (rows + 127) / 128 * 128;  // whole 128-row stages
+  return rows < 128 ? 128 : rows;
+}
+
 int mlp_check_device(const kp1_mlp* m) {
   HIP_TRY(hipSetDevice(m->device));
+  return KP1_OK;
+}
+
+constexpr size_t TN_LDS_BYTES = sizeof(float) * 2 * 2 * 128 * (64 + 4);
+
+template <int EPI>
+int launch_nt(const GemmNT& g, hipStream_t stream) {
+  // 256-column workgroups (A read once per row block) when that still fills the chip, else 128-column ones
+  const int row_tiles = (g.M + 63) / 64;
+  const bool wide = (g.N % 256 == 0) && row_tiles * 2 >= 200;
+  const size_t lds_a = sizeof(float) * 64 * (size_t)(g.K + 4);
+  if (wide) {
+    const size_t bytes = lds_a + sizeof(float) * 2 * 256 * LDT;
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel<256, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL((gemm_nt_kernel<256, EPI>), dim3(row_tiles, g.N / 256, 2), dim3(256), bytes, stream, g);
+  } else {
+    const size_t bytes = lds_a + sizeof(float) * 2 * 128 * LDT;
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel<128, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL((gemm_nt_kernel<128, EPI>), dim3(row_tiles, g.N / 128, 2), dim3(256), bytes, stream, g);
+  }
+  return KP1_OK;
+}
+
+int launch_tn(const GemmTN& t, int n_o_tiles, hipStream_t stream) {
+  const dim3 grid((t.B + t.chunk - 1) / t.chunk, n_o_tiles * t.n_i_tiles, 2);
+  if (t.gatherX) {
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), TN_LDS_BYTES, stream, t);
+  } else {
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), TN_LDS_BYTES, stream, t);
+  }
   return KP1_OK;
 }
 
@@ -660,16 +751,15 @@ int launch_forward_layers(kp1_mlp* m, const float* obs, int obs_stride, const in
   g.C = m->h1; g.ldc = Hp; g.strideC = act_stride;
   g.aux = nullptr; g.strideAux = 0; g.colsum = nullptr; g.strideColsum = 0;
   g.M = n; g.N = Hp; g.K = INP; g.Kreal = obs_stride >= INP ? INP : IN;
-  const bool small = n <= 8192;  // more, smaller row tiles when the batch cannot fill 256 CUs with 128-row tiles
-  if (small) hipLaunchKernelGGL((gemm_nt_kernel<64, EPI_BIAS_TANH>), dim3((n + 63) / 64, Hp / BN, 2), dim3(256), 0, stream, g);
-  else hipLaunchKernelGGL((gemm_nt_kernel<128, EPI_BIAS_TANH>), dim3((n + 127) / 128, Hp / BN, 2), dim3(256), 0, stream, g);
+  int rc = launch_nt<EPI_BIAS_TANH>(g, stream);
+  if (rc != KP1_OK) return rc;
   g.A = m->h1; g.lda = Hp; g.strideA = act_stride; g.gather = nullptr;
   g.W = m->k.w2; g.strideW = (int64_t)Hp * Hp;
   g.bias = m->k.b2;
   g.C = m->h2;
   g.K = Hp; g.Kreal = Hp;
-  if (small) hipLaunchKernelGGL((gemm_nt_kernel<64, EPI_BIAS_TANH>), dim3((n + 63) / 64, Hp / BN, 2), dim3(256), 0, stream, g);
-  else hipLaunchKernelGGL((gemm_nt_kernel<128, EPI_BIAS_TANH>), dim3((n + 127) / 128, Hp / BN, 2), dim3(256), 0, stream, g);
+  rc = launch_nt<EPI_BIAS_TANH>(g, stream);
+  if (rc != KP1_OK) return rc;
   HIP_TRY(hipGetLastError());
   return KP1_OK;
 }
@@ -807,26 +897,27 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
     g.colsum = grad_out + L.p_b1;
     g.strideColsum = L.v_b1 - L.p_b1;
   }
-  if (n <= 8192) hipLaunchKernelGGL((gemm_nt_kernel<64, EPI_DTANH>), dim3((n + 63) / 64, Hp / BN, 2), dim3(256), 0, stream, g);
-  else hipLaunchKernelGGL((gemm_nt_kernel<128, EPI_DTANH>), dim3((n + 127) / 128, Hp / BN, 2), dim3(256), 0, stream, g);
+  rc = launch_nt<EPI_DTANH>(g, stream);
+  if (rc != KP1_OK) return rc;
 
   // weight gradients (split over the batch axis)
   GemmTN t{};
   t.B = n;
-  t.chunk = n >= 4096 ? 512 : 256;
-  const int n_chunks = (n + t.chunk - 1) / t.chunk;
+  t.chunk = tn_chunk_rows(n, Hp);
   // dW2[o][i] = sum_b dZ2[b][o] h1[b][i]
   t.D = m->dz2; t.ldd = Hp; t.strideD = act_stride;
   t.X = m->h1; t.ldx = Hp; t.strideX = act_stride; t.gatherX = nullptr;
   t.G = grad_out + L.p_w2; t.ldg = H; t.strideG = L.v_w2 - L.p_w2;
-  t.Mreal = H; t.Nreal = H; t.Nload = Hp; t.n_i_tiles = Hp / 128;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(n_chunks, (Hp / 128) * t.n_i_tiles, 2), dim3(256), 0, stream, t);
+  t.Mreal = H; t.Nreal = H; t.Nload = Hp; t.n_i_tiles = Hp / 64;
+  rc = launch_tn(t, Hp / 64, stream);
+  if (rc != KP1_OK) return rc;
   // dW1[o][i] = sum_b dZ1[b][o] x[b][i]   (i < 56)
   t.D = m->dz1;
   t.X = obs; t.ldx = obs_stride; t.strideX = 0; t.gatherX = idx;
   t.G = grad_out + L.p_w1; t.ldg = IN; t.strideG = L.v_w1 - L.p_w1;
   t.Nreal = IN; t.Nload = obs_stride >= INP ? INP : IN; t.n_i_tiles = 1;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(n_chunks, Hp / 128, 2), dim3(256), 0, stream, t);
+  rc = launch_tn(t, Hp / 64, stream);
+  if (rc != KP1_OK) return rc;
   HIP_TRY(hipGetLastError());
   return KP1_OK;
 }
@@ -846,7 +937,6 @@ int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32
   rc = launch_forward_layers(m, obs, obs_stride, nullptr, n, stream);  // fills h1/h2 with real activations
   if (rc != KP1_OK) return rc;
   HIP_TRY(hipMemcpyAsync(m->dz2, m->h2, sizeof(float) * 2 * (size_t)act_stride, hipMemcpyDeviceToDevice, stream));
-  const bool small = n <= 8192;
   auto time_it = [&](int which) -> int {
     HIP_TRY(hipEventRecord(e0, stream));
     for (int it = 0; it < iters; ++it) {
@@ -855,25 +945,22 @@ int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32
       if (which == 0) {
         g.A = m->h1; g.lda = Hp; g.strideA = act_stride; g.W = m->k.w2; g.strideW = (int64_t)Hp * Hp; g.bias = m->k.b2; g.strideBias = Hp;
         g.C = m->h2; g.K = Hp; g.Kreal = Hp;
-        if (small) hipLaunchKernelGGL((gemm_nt_kernel<64, EPI_BIAS_TANH>), dim3((n + 63) / 64, Hp / BN, 2), dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((gemm_nt_kernel<128, EPI_BIAS_TANH>), dim3((n + 127) / 128, Hp / BN, 2), dim3(256), 0, stream, g);
+        if (launch_nt<EPI_BIAS_TANH>(g, stream) != KP1_OK) return KP1_ERR_NO_DEVICE;
       } else if (which == 1) {
         g.A = m->dz2; g.lda = Hp; g.strideA = act_stride; g.W = m->k.w2t; g.strideW = (int64_t)Hp * Hp; g.C = m->dz1; g.aux = m->h1;
         g.strideAux = act_stride; g.K = Hp; g.Kreal = Hp;
-        if (small) hipLaunchKernelGGL((gemm_nt_kernel<64, EPI_DTANH>), dim3((n + 63) / 64, Hp / BN, 2), dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((gemm_nt_kernel<128, EPI_DTANH>), dim3((n + 127) / 128, Hp / BN, 2), dim3(256), 0, stream, g);
+        if (launch_nt<EPI_DTANH>(g, stream) != KP1_OK) return KP1_ERR_NO_DEVICE;
       } else if (which == 2) {
         GemmTN t{};
-        t.B = n; t.chunk = n >= 4096 ? 512 : 256;
+        t.B = n; t.chunk = tn_chunk_rows(n, Hp);
         t.D = m->dz2; t.ldd = Hp; t.strideD = act_stride; t.X = m->h1; t.ldx = Hp; t.strideX = act_stride;
         t.G = m->dz1; t.ldg = Hp; t.strideG = act_stride;  // scratch target (dz1 is rewritten by kernel 1 anyway)
-        t.Mreal = Hp; t.Nreal = Hp; t.Nload = Hp; t.n_i_tiles = Hp / 128;
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3((n + t.chunk - 1) / t.chunk, (Hp / 128) * t.n_i_tiles, 2), dim3(256), 0, stream, t);
+        t.Mreal = Hp; t.Nreal = Hp; t.Nload = Hp; t.n_i_tiles = Hp / 64;
+        if (launch_tn(t, Hp / 64, stream) != KP1_OK) return KP1_ERR_NO_DEVICE;
       } else {
         g.A = obs; g.lda = obs_stride; g.strideA = 0; g.W = m->k.w1p; g.strideW = (int64_t)Hp * INP; g.bias = m->k.b1; g.strideBias = Hp;
         g.C = m->h1; g.K = INP; g.Kreal = obs_stride >= INP ? INP : IN;
-        if (small) hipLaunchKernelGGL((gemm_nt_kernel<64, EPI_BIAS_TANH>), dim3((n + 63) / 64, Hp / BN, 2), dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((gemm_nt_kernel<128, EPI_BIAS_TANH>), dim3((n + 127) / 128, Hp / BN, 2), dim3(256), 0, stream, g);
+        if (launch_nt<EPI_BIAS_TANH>(g, stream) != KP1_OK) return KP1_ERR_NO_DEVICE;
       }
     }
     HIP_TRY(hipEventRecord(e1, stream));
