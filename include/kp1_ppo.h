@@ -96,16 +96,19 @@ int kp1_mlp_forward(kp1_mlp* m, const float* obs, int32_t obs_stride, int32_t n,
  * NULL = rows 0..n).  grad_out f32 [num_params] receives d loss / d params in SB3 order (overwritten), with
  *   loss = sum_i[-min(r_i A_i, clip(r_i, 1-c, 1+c) A_i)] * inv_count + vf_coef * sum_i (R_i - V_i)^2 * inv_count - ent_coef * H,
  * r = exp(logp - old_logp), H = entropy of the diagonal Gaussian (state independent).
- * stats_out f32[4] += (policy_loss, value_loss, entropy, approx_kl) of this minibatch. */
+ * stats_out f32[4] += (policy_loss, value_loss, entropy, approx_kl) of this minibatch.
+ * Every producer kernel writes per-workgroup partials with plain stores and one finalize kernel sums them in a fixed order:
+ * no float atomics touch a gradient, results are bitwise reproducible.  grad_is_zero is accepted for ABI stability and ignored. */
 int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const int64_t* idx, int32_t n, const float* actions,
                       const float* old_log_prob, const float* advantages, const float* returns, float adv_mean, float adv_inv_std,
                       const float* adv_stats_dev, float clip_range, float ent_coef, float vf_coef, float inv_count, float* grad_out,
-                      float* stats_out, void* stream);
+                      float* stats_out, int32_t grad_is_zero, void* stream);
 
-/* clip_grad_norm_(max_norm) + Adam(beta 0.9/0.999, eps) step on the flat vectors, then repack the kernel-format weights.
- * step = 1-based Adam step count. */
-int kp1_mlp_adam_step(kp1_mlp* m, float* params, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float eps,
-                      float max_grad_norm, int32_t step, void* stream);
+/* clip_grad_norm_(max_norm) + Adam(beta 0.9/0.999, eps) step on the flat vectors; the same pass repacks the kernel-format
+ * weights.  step = 1-based Adam step count.  flags bit 1 (value 2): grad is untouched since the kp1_mlp_loss_grad call that
+ * produced it (no all-reduce in between), so the norm partials that call left are reused instead of a reduction launch. */
+int kp1_mlp_adam_step(kp1_mlp* m, float* params, float* grad, float* exp_avg, float* exp_avg_sq, float lr, float eps,
+                      float max_grad_norm, int32_t step, int32_t flags, void* stream);
 
 /* HIP-event timing of the three MFMA GEMM kernels at minibatch size n (for bench.py's roofline block): runs each kernel
  * `iters` times back to back on `stream` between hipEventRecord pairs and returns the mean duration in milliseconds:

@@ -24,6 +24,7 @@
 using kp1::fail;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: arrays of it are reliably scalar-replaced (HIP's float4 struct was not)
 
 namespace {
 
@@ -33,6 +34,18 @@ constexpr float LOG_SQRT_2PI = 0.9189385332046727f;
 
 enum { EPI_BIAS_TANH = 0, EPI_DTANH = 1 };
 
+// Branch-free tanh (the epilogue runs one wave per SIMD, so every VALU slot is exposed; ocml's tanhf costs ~45
+// instructions plus divergent branches).  |x| < 0.25: odd Taylor polynomial through x^9 (truncation < 1e-8 relative);
+// else 1 - 2 / (2^(2 log2(e) |x|) + 1) on v_exp_f32 / v_rcp_f32.  Absolute error <= ~2e-7 (fp32 rounding of values near 1),
+// checked against torch.tanh in tests/test_ppo_kernels_gpu.py.
+__device__ __forceinline__ float kp_tanh(float x) {
+  const float ax = fabsf(x), x2 = x * x;
+  const float small = ax * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 0.021869488536155203f, -0.05396825396825397f), 0.13333333333333333f), -0.3333333333333333f), 1.0f);
+  const float t = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);
+  const float big = fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
+  return copysignf(ax < 0.25f ? small : big, x);
+}
+
 struct GemmNT {
   const float* A; int64_t lda; int64_t strideA;       // [M][lda], per-net stride
   const int64_t* gather;                               // optional row indices into A (shared by both nets)
@@ -40,7 +53,8 @@ struct GemmNT {
   const float* bias; int64_t strideBias;               // [N]
   float* C; int64_t ldc; int64_t strideC;              // [M][ldc]
   const float* aux; int64_t strideAux;                 // EPI_DTANH: activation H at C's coordinates (ld = ldc)
-  float* colsum; int64_t strideColsum;                 // EPI_DTANH: += column sums of C (bias gradient), may be null
+  float* colsum; int64_t strideColsum;                 // EPI_DTANH: per-row-block column sums of C (bias-gradient partials)
+                                                       //   written to colsum[blockIdx.x * 2*strideColsum + z*strideColsum + n]
   int M, N, K, Kreal;                                  // K multiple of 32; A columns >= Kreal read as 0
 };
 
@@ -48,14 +62,17 @@ struct GemmNT {
 // batches) for one net.  The 64 x K block of A is loaded ONCE and stays in LDS; W streams through a double-buffered
 // [BN][32] stage, so every stage carries 4096 MFMA cycles per wave (BN = 256) against one L2 round trip, and A is
 // never re-read.  4 waves, each 64 columns wide (2 MFMA column blocks) and RB row blocks tall.
-template <int BN, int EPI>
-__global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmNT g) {
+// amdgpu_waves_per_eu(1, 2): the 140 KB LDS footprint allows one workgroup (one wave per SIMD) per CU anyway; without
+// the hint hipcc spills the prefetch registers to scratch to stay under the 256-register budget of two waves per SIMD.
+template <int BN, int EPI, int K>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) gemm_nt_kernel(const GemmNT g) {
   constexpr int BM = 64;
+  constexpr int KQ = K / 4, A_LOADS = BM * KQ / 256;  // float4 per A row / per thread: all issued before any is used
   constexpr int WN = BN / 64, WM = 4 / WN;
   constexpr int RB = BM / WM / 32, CB = 2;
   constexpr int W_LOADS = BN * 8 / 256;
   extern __shared__ float lds[];
-  const int lda_s = g.K + 4;                 // LDS pitch of the resident A block (bank-conflict-free b128 reads)
+  constexpr int lda_s = K + 4;               // LDS pitch of the resident A block (bank-conflict-free b128 reads)
   float* As = lds;
   float* Ws0 = lds + BM * lda_s;
   float* Ws1 = Ws0 + BN * LDT;
@@ -63,35 +80,52 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmNT g) {
   const int z = blockIdx.z;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const float* __restrict__ A = g.A + z * g.strideA;
-  const float* __restrict__ W = g.W + z * g.strideW + (int64_t)n0 * g.K;
+  const float* __restrict__ W = g.W + z * g.strideW + (int64_t)n0 * K;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN;
 
-  // ---- prologue: first W stage to registers, whole A block to LDS
-  float4 rw[W_LOADS];
-#pragma unroll
-  for (int j = 0; j < W_LOADS; ++j) {
-    const int f = tid + 256 * j;
-    rw[j] = *reinterpret_cast<const float4*>(W + (int64_t)(f >> 3) * g.K + 4 * (f & 7));
+  // ---- prologue: W stages 0 and 1 to registers, whole A block to LDS.  W is prefetched TWO stages ahead (register
+  // sets rwa / rwb alternate): with one wave per SIMD nothing else hides an L2 round trip, and one 4096-cycle stage
+  // of cover was not enough under 256 workgroups streaming the same W.
+  constexpr int KT = K / BK;
+  f32x4 rwa[W_LOADS], rwb[W_LOADS];
+#define KP1_NT_WLOAD(dst, stage)                                                                        \
+  {                                                                                                     \
+    const int kk = ((stage) < KT ? (stage) : KT - 1) * BK;                                              \
+    _Pragma("unroll") for (int j = 0; j < W_LOADS; ++j) {                                               \
+      const int f = tid + 256 * j;                                                                      \
+      dst[j] = *reinterpret_cast<const f32x4*>(W + (int64_t)(f >> 3) * K + kk + 4 * (f & 7));           \
+    }                                                                                                   \
   }
+#define KP1_NT_WSTORE(src, ws)                                                                          \
+  _Pragma("unroll") for (int j = 0; j < W_LOADS; ++j) {                                                 \
+    const int f = tid + 256 * j;                                                                        \
+    *reinterpret_cast<f32x4*>((ws) + (f >> 3) * LDT + 4 * (f & 7)) = src[j];                            \
+  }
+  KP1_NT_WLOAD(rwa, 0)
+  KP1_NT_WLOAD(rwb, 1)
   {
-    const int kq = g.K >> 2;                 // float4 per A row
-    for (int f = tid; f < BM * kq; f += 256) {
-      const int row = f / kq, c4 = f - row * kq;
-      const int m = m0 + row, k = 4 * c4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < g.M && k < g.Kreal) {
-        const int64_t src = g.gather ? g.gather[m] : (int64_t)m;
-        v = *reinterpret_cast<const float4*>(A + src * g.lda + k);
-      }
-      *reinterpret_cast<float4*>(As + row * lda_s + k) = v;
+    // branch-free and fully unrolled: (gather indices) -> all A_LOADS row loads in flight -> mask -> LDS
+    int64_t arow[A_LOADS];
+    f32x4 av[A_LOADS];
+#pragma unroll
+    for (int j = 0; j < A_LOADS; ++j) {
+      const int m = min(m0 + (tid + 256 * j) / KQ, g.M - 1);
+      arow[j] = g.gather ? g.gather[m] : (int64_t)m;
+    }
+#pragma unroll
+    for (int j = 0; j < A_LOADS; ++j) {
+      const int k = 4 * ((tid + 256 * j) % KQ);
+      av[j] = *reinterpret_cast<const f32x4*>(A + arow[j] * g.lda + (k < g.Kreal ? k : 0));
+    }
+#pragma unroll
+    for (int j = 0; j < A_LOADS; ++j) {
+      const int f = tid + 256 * j, row = f / KQ, k = 4 * (f % KQ);
+      const float keep = (m0 + row < g.M && k < g.Kreal) ? 1.f : 0.f;
+      *reinterpret_cast<f32x4*>(As + row * lda_s + k) = av[j] * keep;
     }
   }
-#pragma unroll
-  for (int j = 0; j < W_LOADS; ++j) {
-    const int f = tid + 256 * j;
-    *reinterpret_cast<float4*>(Ws0 + (f >> 3) * LDT + 4 * (f & 7)) = rw[j];
-  }
+  KP1_NT_WSTORE(rwa, Ws0)
   __syncthreads();
 
   f32x16 acc[RB][CB];
@@ -102,104 +136,97 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmNT g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
 
-  const int KT = g.K / BK;
   const float* as_base = As + (wr * (BM / WM) + (lane & 31)) * lda_s + 4 * (lane >> 5);
-  for (int kt = 0; kt < KT; ++kt) {
-    const float* ws_cur = (kt & 1) ? Ws1 : Ws0;
-    float* ws_nxt = (kt & 1) ? Ws0 : Ws1;
-    // unconditional prefetch (the last iteration re-reads its own stage): keeping the loads and the LDS stores out of
-    // conditional blocks lets hipcc hold rw[] in registers; inside `if`s it spills the array to scratch and waits
-    // for the loads before the MFMAs, which destroys the overlap
-    const int k_next = (kt + 1 < KT ? kt + 1 : kt) * BK;
-#pragma unroll
-    for (int j = 0; j < W_LOADS; ++j) {
-      const int f = tid + 256 * j;
-      rw[j] = *reinterpret_cast<const float4*>(W + (int64_t)(f >> 3) * g.K + k_next + 4 * (f & 7));
-    }
-    const float* as = as_base + kt * BK;
-    const float* ws = ws_cur + (wc * 64 + (lane & 31)) * LDT + 4 * (lane >> 5);
-#pragma unroll
-    for (int kg = 0; kg < BK / 8; ++kg) {
-      float4 a[RB], b[CB];
-#pragma unroll
-      for (int r = 0; r < RB; ++r) a[r] = *reinterpret_cast<const float4*>(as + r * 32 * lda_s + kg * 8);
-#pragma unroll
-      for (int c = 0; c < CB; ++c) b[c] = *reinterpret_cast<const float4*>(ws + c * 32 * LDT + kg * 8);
-#pragma unroll
-      for (int r = 0; r < RB; ++r)
-#pragma unroll
-        for (int c = 0; c < CB; ++c) {
-          acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].x, b[c].x, acc[r][c], 0, 0, 0);
-          acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].y, b[c].y, acc[r][c], 0, 0, 0);
-          acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].z, b[c].z, acc[r][c], 0, 0, 0);
-          acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].w, b[c].w, acc[r][c], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < W_LOADS; ++j) {
-      const int f = tid + 256 * j;
-      *reinterpret_cast<float4*>(ws_nxt + (f >> 3) * LDT + 4 * (f & 7)) = rw[j];
-    }
+#define KP1_NT_COMPUTE(kt_, ws_cur_)                                                                    \
+  {                                                                                                     \
+    const float* as = as_base + (kt_) * BK;                                                             \
+    const float* ws = (ws_cur_) + (wc * 64 + (lane & 31)) * LDT + 4 * (lane >> 5);                      \
+    _Pragma("unroll") for (int kg = 0; kg < BK / 8; ++kg) {                                             \
+      float4 a[RB], b[CB];                                                                              \
+      _Pragma("unroll") for (int r = 0; r < RB; ++r) a[r] = *reinterpret_cast<const float4*>(as + r * 32 * lda_s + kg * 8); \
+      _Pragma("unroll") for (int c = 0; c < CB; ++c) b[c] = *reinterpret_cast<const float4*>(ws + c * 32 * LDT + kg * 8);   \
+      _Pragma("unroll") for (int r = 0; r < RB; ++r)                                                    \
+        _Pragma("unroll") for (int c = 0; c < CB; ++c) {                                                \
+          acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].x, b[c].x, acc[r][c], 0, 0, 0);         \
+          acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].y, b[c].y, acc[r][c], 0, 0, 0);         \
+          acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].z, b[c].z, acc[r][c], 0, 0, 0);         \
+          acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].w, b[c].w, acc[r][c], 0, 0, 0);         \
+        }                                                                                               \
+    }                                                                                                   \
+  }
+  // stage kt computes from LDS buffer (kt & 1); registers hold stage kt+1 (written to the other buffer at the end of
+  // the stage) while the loads of stage kt+2 are issued at its start.  Unrolled by two so the register sets are static.
+  for (int kt = 0; kt < KT; kt += 2) {
+    KP1_NT_WLOAD(rwa, kt + 2)          // rwa is free: stage kt already sits in Ws0
+    KP1_NT_COMPUTE(kt, Ws0)
+    KP1_NT_WSTORE(rwb, Ws1)            // stage kt+1
+    __syncthreads();
+    KP1_NT_WLOAD(rwb, kt + 3)          // KT is even (K % 64 == 0, checked on the host): no conditional, no spills
+    KP1_NT_COMPUTE(kt + 1, Ws1)
+    KP1_NT_WSTORE(rwa, Ws0)            // stage kt+2
     __syncthreads();
   }
+#undef KP1_NT_WLOAD
+#undef KP1_NT_WSTORE
+#undef KP1_NT_COMPUTE
 
-  // Epilogue in three passes so no memory operation is pending while tanhf's divergent blocks run: (1) issue every
-  // load, (2) compute in registers, (3) issue every store.  (Interleaving them makes hipcc place s_waitcnt vmcnt(0)
-  // in each conditional block, which serialises the stores: 32 dependent store round trips per lane.)
+  // ---- epilogue: accumulators -> LDS (row-major [64][BN+4], reusing the A/W staging space) -> each thread owns
+  // float4 column groups of 16 B, so bias/aux loads and the C stores are fully coalesced dwordx4 (the MFMA register
+  // layout would give 64 scalar stores per lane, which are issue-bound with one wave per SIMD).
+  constexpr int LDC = BN + 4, CQ = BN / 4, C_ITERS = BM * CQ / 256;
+  float* Cs = lds;
+#pragma unroll
+  for (int c = 0; c < CB; ++c)
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wr * (BM / WM) + r * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        Cs[row * LDC + wc * 64 + c * 32 + (lane & 31)] = acc[r][c][e];
+      }
+  __syncthreads();
   float* __restrict__ C = g.C + z * g.strideC;
-  const int mbase = m0 + wr * (BM / WM) + 4 * (lane >> 5);
-  float bias[CB];
-  float hval[EPI == EPI_DTANH ? CB : 1][RB][16];
+  const int c4 = tid % CQ;                      // fixed column group per thread
+  const int ncol = n0 + 4 * c4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI == EPI_BIAS_TANH) bias4 = *reinterpret_cast<const f32x4*>(g.bias + z * g.strideBias + ncol);
+  f32x4 hv[EPI == EPI_DTANH ? C_ITERS : 1];
+  if constexpr (EPI == EPI_DTANH) {
 #pragma unroll
-  for (int c = 0; c < CB; ++c) {
-    const int n = n0 + wc * 64 + c * 32 + (lane & 31);
-    if constexpr (EPI == EPI_BIAS_TANH) bias[c] = g.bias[z * g.strideBias + n];
-    else {
-      bias[c] = 0.f;
-#pragma unroll
-      for (int r = 0; r < RB; ++r)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = mbase + r * 32 + (e & 3) + 8 * (e >> 2);
-          hval[c][r][e] = m < g.M ? g.aux[z * g.strideAux + (int64_t)m * g.ldc + n] : 0.f;
-        }
+    for (int j = 0; j < C_ITERS; ++j) {
+      const int m = min(m0 + (tid + 256 * j) / CQ, g.M - 1);
+      hv[j] = *reinterpret_cast<const f32x4*>(g.aux + z * g.strideAux + (int64_t)m * g.ldc + ncol);
     }
   }
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < CB; ++c) {
-    float csum = 0.f;
+  for (int j = 0; j < C_ITERS; ++j) {
+    const int row = (tid + 256 * j) / CQ;
+    const int m = m0 + row;
+    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC + 4 * c4);
+    if constexpr (EPI == EPI_BIAS_TANH) {
+      v += bias4;
+      v.x = kp_tanh(v.x); v.y = kp_tanh(v.y); v.z = kp_tanh(v.z); v.w = kp_tanh(v.w);
+    } else {
+      v = v * (1.f - hv[j] * hv[j]);
+      if (m < g.M) csum += v;
+    }
+    if (m < g.M) *reinterpret_cast<f32x4*>(C + (int64_t)m * g.ldc + ncol) = v;
+  }
+  if constexpr (EPI == EPI_DTANH) {
+    if (g.colsum) {
+      // bias-gradient partial of this row block: threads tid, tid + CQ, ... own the same column group; combine them in
+      // LDS (space behind the C tile) and write one row of partials with plain stores (no contended atomics)
+      float* red = lds + BM * LDC;
+      *reinterpret_cast<f32x4*>(red + (tid / CQ) * BN + 4 * c4) = csum;
+      __syncthreads();
+      if (tid < BN) {
+        float t = 0.f;
 #pragma unroll
-    for (int r = 0; r < RB; ++r)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float v = acc[r][c][e];
-        if constexpr (EPI == EPI_BIAS_TANH) {
-          v = tanhf(v + bias[c]);
-        } else {
-          const float h = hval[c][r][e];
-          v = v * (1.f - h * h);
-          csum += v;  // rows >= M carry zero accumulators (their A rows were loaded as 0)
-        }
-        acc[r][c][e] = v;
-      }
-    if constexpr (EPI == EPI_DTANH) {
-      if (g.colsum) {
-        const int n = n0 + wc * 64 + c * 32 + (lane & 31);
-        csum += __shfl_xor(csum, 32);
-        if (lane < 32) atomicAdd(g.colsum + z * g.strideColsum + n, csum);
+        for (int k = 0; k < 256 / CQ; ++k) t += red[k * BN + tid];
+        g.colsum[(int64_t)blockIdx.x * 2 * g.strideColsum + z * g.strideColsum + n0 + tid] = t;
       }
     }
-  }
-#pragma unroll
-  for (int c = 0; c < CB; ++c) {
-    const int n = n0 + wc * 64 + c * 32 + (lane & 31);
-#pragma unroll
-    for (int r = 0; r < RB; ++r)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = mbase + r * 32 + (e & 3) + 8 * (e >> 2);
-        if (m < g.M) C[(int64_t)m * g.ldc + n] = acc[r][c][e];
-      }
   }
 }
 
@@ -207,22 +234,24 @@ struct GemmTN {
   const float* D; int64_t ldd; int64_t strideD;     // dZ [B][ldd] : output-feature columns ("M" of the product)
   const float* X; int64_t ldx; int64_t strideX;     // previous activations [B][ldx] : input-feature columns ("N")
   const int64_t* gatherX;                            // optional row gather for X (layer 1 reads the obs buffer)
-  float* G; int64_t ldg; int64_t strideG;           // dW [Mreal][ldg] += D^T X  (atomic accumulate)
-  int B, Mreal, Nreal, Nload;                        // G rows o < Mreal, columns i < Nreal; X columns < Nload are readable
-  int chunk;                                         // rows of B reduced per workgroup (multiple of 32)
+  float* slab;                                       // partial products [chunk][net][Mpad][slab_ld], plain stores
+  int64_t slab_ld, slab_net_stride, slab_chunk_stride;
+  int B, Nload;                                      // X columns < Nload are readable (the rest of the tile is zero)
+  int chunk;                                         // rows of B reduced per workgroup (multiple of 64)
   int n_i_tiles;
 };
 
-// dW[o][i] += sum_b D[b][o] X[b][i].  Block tile 64(o) x 64(i), 4 waves 2x2, one 32x32 MFMA tile per wave.
-// Both operands are K(b)-major in LDS exactly as they sit in memory (rows of dZ / H), so lane l reads
-// D[b = 2s + (l>>5)][o = wr*32 + (l&31)] and X[b][i = wc*32 + (l&31)]: conflict-free ds_read_b32, no transposes.
-// Stages are 128 batch rows deep (4096 MFMA cycles per wave per stage, double buffered) so the next stage's loads
-// are covered.  Small tiles + long batch chunks keep 256 workgroups busy while the split-K atomic traffic stays at
-// n_chunks * H*H*4 B (4 MB at B = 8192, H = 256) instead of 16.8 MB with 128x128 tiles.
+// partial[chunk][net][o][i] = sum_{b in chunk} D[b][o] X[b][i].   Block tile 128(o) x 128(i), 4 waves 2x2, wave tile
+// 64x64 with interleaved row/col blocks (o = base + 2*(l&31) + rb): one ds_read_b64 per operand and step feeds two MFMA
+// row (column) blocks.  Both operands sit in LDS exactly as in memory (batch-row major), no transposes.  128x128 tiles
+// need 32 FLOP per byte streamed from L2 (64x64 tiles: 16 FLOP/B, which demanded ~10 TB/s and stalled every stage).
+// Stages are 64 batch rows (8192 MFMA cycles per wave), double buffered.  The batch axis is split over workgroups; each
+// writes its partial tile with plain coalesced stores and tn_reduce_kernel sums the partials in fixed order, so weight
+// gradients are bitwise reproducible (float atomics are not).
 // grid: x = B chunk, y = o_tile * n_i_tiles + i_tile, z = net.
 template <bool GATHER>
-__global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmTN g) {
-  constexpr int TB = 128, TT = 64, LDW = TT + 4, LOADS = TB * TT / 4 / 256;  // 8 float4 per thread per operand
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) gemm_tn_kernel(const GemmTN g) {
+  constexpr int TB = 64, TT = 128, LDW = TT + 4, LOADS = TB * TT / 4 / 256;  // 8 float4 per thread per operand
   extern __shared__ float lds[];
   const int z = blockIdx.z;
   const int o0 = (blockIdx.y / g.n_i_tiles) * TT, i0 = (blockIdx.y % g.n_i_tiles) * TT;
@@ -232,78 +261,97 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmTN g) {
   const float* __restrict__ X = g.X + z * g.strideX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int srow = tid >> 4, sc4 = tid & 15;  // staging: f = tid + 256*j -> row = srow + 16*j, c4 = sc4
-  // columns of X past Nload are not readable (layer 1: 56 or 64 obs columns under a 64-wide tile): clamp + zero
+  const int srow = tid >> 5, sc4 = tid & 31;  // staging: f = tid + 256*j -> row = srow + 8*j, c4 = sc4
   const bool x_col_ok = i0 + 4 * sc4 < g.Nload;
   const int x_col = x_col_ok ? i0 + 4 * sc4 : 0;
   const int b_last = b_end - 1;
 
-  // Branch-free staging: out-of-range rows are clamped to the last valid row and zeroed after the load, so all 16
-  // global loads of a stage are issued back to back (conditional blocks made hipcc wait vmcnt(0) between them).
-  float4 rd[LOADS], rx[LOADS];
+  // Branch-free staging: out-of-range rows are clamped to the last valid row and zeroed at LDS-store time, so all 16
+  // global loads of a stage are issued back to back and nothing waits on them until the stage's MFMAs are issued.
+  f32x4 rd[LOADS], rx[LOADS];
 #define KP1_TN_LOAD(b0)                                                                                   \
   {                                                                                                       \
     int64_t xrow[LOADS];                                                                                  \
     _Pragma("unroll") for (int j = 0; j < LOADS; ++j) {                                                   \
-      const int b = min((b0) + srow + 16 * j, b_last);                                                    \
+      const int b = min((b0) + srow + 8 * j, b_last);                                                     \
       xrow[j] = GATHER ? g.gatherX[b] : (int64_t)b;                                                       \
     }                                                                                                     \
     _Pragma("unroll") for (int j = 0; j < LOADS; ++j) {                                                   \
-      const int b = min((b0) + srow + 16 * j, b_last);                                                    \
-      rd[j] = *reinterpret_cast<const float4*>(D + (int64_t)b * g.ldd + 4 * sc4);                         \
-      rx[j] = *reinterpret_cast<const float4*>(X + xrow[j] * g.ldx + x_col);                              \
+      const int b = min((b0) + srow + 8 * j, b_last);                                                     \
+      rd[j] = *reinterpret_cast<const f32x4*>(D + (int64_t)b * g.ldd + 4 * sc4);                          \
+      rx[j] = *reinterpret_cast<const f32x4*>(X + xrow[j] * g.ldx + x_col);                               \
     }                                                                                                     \
   }
-  // the zeroing of clamped rows happens here, at LDS-store time, so nothing touches the loaded registers (and no
-  // vmcnt wait is needed) until the MFMAs of the current stage have been issued
 #define KP1_TN_STORE(buf, b0)                                                                             \
   _Pragma("unroll") for (int j = 0; j < LOADS; ++j) {                                                     \
-    const float keep = ((b0) + srow + 16 * j <= b_last) ? 1.f : 0.f;                                      \
+    const float keep = ((b0) + srow + 8 * j <= b_last) ? 1.f : 0.f;                                       \
     const float keepx = x_col_ok ? keep : 0.f;                                                            \
-    float* base = lds + (buf) * 2 * TB * LDW + (srow + 16 * j) * LDW + 4 * sc4;                           \
-    *reinterpret_cast<float4*>(base) = make_float4(rd[j].x * keep, rd[j].y * keep, rd[j].z * keep, rd[j].w * keep);          \
-    *reinterpret_cast<float4*>(base + TB * LDW) = make_float4(rx[j].x * keepx, rx[j].y * keepx, rx[j].z * keepx, rx[j].w * keepx); \
+    float* base = lds + (buf) * 2 * TB * LDW + (srow + 8 * j) * LDW + 4 * sc4;                            \
+    *reinterpret_cast<f32x4*>(base) = rd[j] * keep;                                                       \
+    *reinterpret_cast<f32x4*>(base + TB * LDW) = rx[j] * keepx;                                           \
   }
 
-  f32x16 acc;
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
 
   const int KT = (b_end - b_begin + TB - 1) / TB;
-  if (KT <= 0) return;  // whole workgroup (uniform): nothing to reduce
-  KP1_TN_LOAD(b_begin)
-  KP1_TN_STORE(0, b_begin)
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    KP1_TN_LOAD(b_begin + (kt + 1) * TB)  // past the chunk end: clamped rows, zeroed
-    const float* ds = lds + buf * 2 * TB * LDW + (lane >> 5) * LDW + wr * 32 + (lane & 31);
-    const float* xs = ds + TB * LDW + (wc - wr) * 32;
-#pragma unroll
-    for (int s0 = 0; s0 < TB / 2; s0 += 8) {
-      float av[8], xv[8];  // LDS reads of 8 steps in flight ahead of their MFMAs
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        av[u] = ds[2 * (s0 + u) * LDW];
-        xv[u] = xs[2 * (s0 + u) * LDW];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], xv[u], acc, 0, 0, 0);
-      // schedule: the 16 LDS reads of this group first, then its 8 MFMAs (otherwise hipcc waits lgkmcnt(0) per pair)
-      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-    }
-    KP1_TN_STORE(buf ^ 1, b_begin + (kt + 1) * TB)
+  if (KT > 0) {  // uniform per workgroup
+    KP1_TN_LOAD(b_begin)
+    KP1_TN_STORE(0, b_begin)
     __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+      const int buf = kt & 1;
+      KP1_TN_LOAD(b_begin + (kt + 1) * TB)  // past the chunk end: clamped rows, zeroed at store time
+      const float* ds = lds + buf * 2 * TB * LDW + (lane >> 5) * LDW + wr * 64 + 2 * (lane & 31);
+      const float* xs = lds + buf * 2 * TB * LDW + TB * LDW + (lane >> 5) * LDW + wc * 64 + 2 * (lane & 31);
+#pragma unroll
+      for (int s0 = 0; s0 < TB / 2; s0 += 4) {
+        float2 av[4], xv[4];  // LDS reads of 4 steps (16 MFMAs) in flight ahead of their use
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          av[u] = *reinterpret_cast<const float2*>(ds + 2 * (s0 + u) * LDW);
+          xv[u] = *reinterpret_cast<const float2*>(xs + 2 * (s0 + u) * LDW);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, xv[u].x, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, xv[u].y, acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, xv[u].x, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, xv[u].y, acc[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // 8 DS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // then their 16 MFMAs
+      }
+      KP1_TN_STORE(buf ^ 1, b_begin + (kt + 1) * TB)
+      __syncthreads();
+    }
   }
 #undef KP1_TN_LOAD
 #undef KP1_TN_STORE
-  float* __restrict__ G = g.G + z * g.strideG;
-  const int i = i0 + wc * 32 + (lane & 31);
+  // partial tile -> slab (zeros when this chunk had no rows): transposed through LDS so rows are written as float4
+  constexpr int LDP = TT + 4;
+  float* Ps = lds;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int o = o0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-    if (o < g.Mreal && i < g.Nreal) atomicAdd(G + (int64_t)o * g.ldg + i, acc[e]);
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int o = wr * 64 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) + r;
+        Ps[o * LDP + wc * 64 + 2 * (lane & 31) + c] = acc[r][c][e];
+      }
+  __syncthreads();
+  float* __restrict__ P = g.slab + blockIdx.x * g.slab_chunk_stride + z * g.slab_net_stride;
+#pragma unroll
+  for (int j = 0; j < TT * TT / 4 / 256; ++j) {
+    const int f = tid + 256 * j, o = f >> 5, q = f & 31;
+    const int col = i0 + 4 * q;
+    if (col < g.slab_ld) *reinterpret_cast<f32x4*>(P + (int64_t)(o0 + o) * g.slab_ld + col) = *reinterpret_cast<const f32x4*>(Ps + o * LDP + 4 * q);
   }
 }
 
@@ -323,10 +371,9 @@ struct HeadArgs {
   float clip_range, ent_coef, vf_coef, inv_count;
   // training outputs
   float* dz2;             // [2][n][Hp]
-  float* g_w3;            // [8][H] in SB3 layout: action_net.weight [7][H] then value_net.weight [1][H] (pointers below)
-  float* g_action_w; float* g_action_b; float* g_value_w; float* g_value_b; float* g_log_std; float* g_b2p; float* g_b2v;
+  float* hpart;           // per-block partials [n_blocks][hpart_stride]: dW action [7][Hp], dW value [Hp], db2 pi [Hp], db2 vf [Hp],
+  int hpart_stride;       //   then 8 head-bias grads, 7 log_std grads, 3 loss sums (policy, value, kl)
   int H;                  // real hidden (<= Hp)
-  float* stats;           // [4]
 };
 
 constexpr int HEAD_ROWS = 32;  // rows per 256-thread block: thread = (row = t/8, out = t%8)
@@ -404,14 +451,25 @@ __global__ void __launch_bounds__(256) adv_partials_kernel(const float* __restri
 
 // heads forward + PPO loss gradient + dZ2 for both nets + head weight/bias gradients
 __global__ void __launch_bounds__(256) head_train_kernel(const HeadArgs a) {
-  // all LDS is one dynamic array (16-B aligned base: head_dot reads w3s as float4; guide G17)
+  // all LDS is one dynamic array (16-B aligned base: head_dot reads float4; guide G17)
   extern __shared__ float smem[];
+  const int hpitch = a.Hp + 4;             // row pitch of the staged activations: conflict-free float4 row reads
   float* w3s = smem;                       // [8][Hp]
   float* dout = smem + HEADS * a.Hp;       // [HEAD_ROWS][8] : d loss / d (mean_0..6, value)
-  float* red = dout + HEAD_ROWS * 8;       // [4]
-  float* adv_ms = red + 4;                 // [2]
+  float* red = dout + HEAD_ROWS * 8;       // [20] small per-block accumulators
+  float* adv_ms = red + 20;                // [2] (+2 pad)
+  float* h2s = adv_ms + 4;                 // [2][HEAD_ROWS][hpitch]: this block's rows of both nets, read from HBM once
   for (int k = threadIdx.x; k < HEADS * a.Hp; k += 256) w3s[k] = a.w3[k];
-  if (threadIdx.x < 4) red[threadIdx.x] = 0.f;
+  {
+    const int q = a.Hp >> 2;               // float4 per row
+    for (int f = threadIdx.x; f < 2 * HEAD_ROWS * q; f += 256) {
+      const int net = f / (HEAD_ROWS * q), rem = f - net * HEAD_ROWS * q, r = rem / q, c4 = rem - r * q;
+      const int grow = min(blockIdx.x * HEAD_ROWS + r, a.n - 1);
+      *reinterpret_cast<float4*>(h2s + (net * HEAD_ROWS + r) * hpitch + 4 * c4) =
+          *reinterpret_cast<const float4*>(a.h2 + net * a.strideH + (int64_t)grow * a.Hp + 4 * c4);
+    }
+  }
+  if (threadIdx.x < 20) red[threadIdx.x] = 0.f;
   // fixed-order parallel reduction of the per-block advantage partials (wave 0; a.n_adv_partials <= 128)
   double ps = 0.0, pss = 0.0;
   if (a.adv_mode == 1 && threadIdx.x < 64) {
@@ -448,10 +506,7 @@ __global__ void __launch_bounds__(256) head_train_kernel(const HeadArgs a) {
   const bool ok = row < a.n;
   const int64_t src = ok ? (a.idx ? a.idx[row] : (int64_t)row) : 0;
   float v = 0.f;
-  if (ok) {
-    const float* h = a.h2 + (out == 7 ? a.strideH : 0) + (int64_t)row * a.Hp;
-    v = head_dot(h, w3s + out * a.Hp, a.Hp) + a.b3[out];
-  }
+  if (ok) v = head_dot(h2s + ((out == 7 ? HEAD_ROWS : 0) + row_l) * hpitch, w3s + out * a.Hp, a.Hp) + a.b3[out];
   // Gaussian log-prob of the stored action under the current policy
   float z = 0.f, inv_sd = 1.f, lp = 0.f;
   if (ok && out < ACT) {
@@ -485,9 +540,9 @@ __global__ void __launch_bounds__(256) head_train_kernel(const HeadArgs a) {
     }
   }
   dout[row_l * 8 + out] = ok ? d : 0.f;
-  // d loss / d log_std_out = sum_rows g_logp (z^2 - 1)  (+ entropy term added once by block 0)
+  // per-block sums over rows of: d loss/d log_std_out, d loss/d head bias_out, loss terms.  Lanes with equal (t & 7) hold
+  // the same `out`: reduce inside the wave by shuffles, across the 4 waves through LDS atomics (uncontended, 4 adders).
   float gls = (ok && out < ACT) ? g_logp * (z * z - 1.f) : 0.f;
-  // reduce over the 32 rows that share `out`: lanes with equal (t & 7) inside a wave, then across the 4 waves via atomics
   gls += __shfl_xor(gls, 8);
   gls += __shfl_xor(gls, 16);
   gls += __shfl_xor(gls, 32);
@@ -495,32 +550,22 @@ __global__ void __launch_bounds__(256) head_train_kernel(const HeadArgs a) {
   dsum += __shfl_xor(dsum, 8);
   dsum += __shfl_xor(dsum, 16);
   dsum += __shfl_xor(dsum, 32);
+  float* small = red;  // [0..3) loss sums, then 8 bias grads at +4, 7 log_std grads at +12  (20 floats, zeroed below)
   if ((threadIdx.x & 63) < 8) {
-    if (out < ACT) {
-      atomicAdd(a.g_log_std + out, gls);
-      atomicAdd(a.g_action_b + out, dsum);
-    } else {
-      atomicAdd(a.g_value_b, dsum);
-    }
+    atomicAdd(&small[4 + out], dsum);
+    if (out < ACT) atomicAdd(&small[12 + out], gls);
   }
   if (out == 7) {
-    atomicAdd(&red[0], pl);
-    atomicAdd(&red[1], vl);
-    atomicAdd(&red[3], kl);
+    atomicAdd(&small[0], pl);
+    atomicAdd(&small[1], vl);
+    atomicAdd(&small[2], kl);
   }
   __syncthreads();
-  if (threadIdx.x == 0 && a.stats) {
-    atomicAdd(a.stats + 0, red[0] * a.inv_count);
-    atomicAdd(a.stats + 1, red[1] * a.inv_count);
-    atomicAdd(a.stats + 3, red[3] * a.inv_count);
-  }
-  if (blockIdx.x == 0 && threadIdx.x < ACT) {
-    atomicAdd(a.g_log_std + threadIdx.x, -a.ent_coef);  // d(-ent_coef * sum_a log_std_a)/d log_std
-    if (threadIdx.x == 0 && a.stats) {
-      float ent = 0.f;
-      for (int k = 0; k < ACT; ++k) ent += 0.5f + LOG_SQRT_2PI + a.log_std[k];
-      atomicAdd(a.stats + 2, ent);
-    }
+  float* part = a.hpart + (int64_t)blockIdx.x * a.hpart_stride;
+  if (threadIdx.x < 19) {
+    const int k = threadIdx.x;  // 0..7 bias grads, 8..14 log_std grads, 15..17 loss sums
+    const float v = k < 8 ? small[4 + k] : (k < 15 ? small[12 + (k - 8)] : small[k - 15]);
+    if (k < 18) part[10 * a.Hp + k] = v;
   }
   // phase 2: one thread per hidden column; dZ2 = (dOut W3) * (1 - h2^2), head weight grads, layer-2 bias grads
   const int rows_here = min(HEAD_ROWS, a.n - blockIdx.x * HEAD_ROWS);
@@ -534,7 +579,7 @@ __global__ void __launch_bounds__(256) head_train_kernel(const HeadArgs a) {
     float gb2p = 0.f, gb2v = 0.f;
     for (int r = 0; r < rows_here; ++r) {
       const int64_t rr = (int64_t)(blockIdx.x * HEAD_ROWS + r) * a.Hp + h;
-      const float hp = a.h2[rr], hv = a.h2[a.strideH + rr];
+      const float hp = h2s[r * hpitch + h], hv = h2s[(HEAD_ROWS + r) * hpitch + h];
       float dp = 0.f;
 #pragma unroll
       for (int o = 0; o < ACT; ++o) {
@@ -551,13 +596,10 @@ __global__ void __launch_bounds__(256) head_train_kernel(const HeadArgs a) {
       gb2p += dzp;
       gb2v += dzv;
     }
-    if (h < a.H) {
 #pragma unroll
-      for (int o = 0; o < ACT; ++o) atomicAdd(a.g_action_w + (int64_t)o * a.H + h, gw[o]);
-      atomicAdd(a.g_value_w + h, gw[7]);
-      atomicAdd(a.g_b2p + h, gb2p);
-      atomicAdd(a.g_b2v + h, gb2v);
-    }
+    for (int o = 0; o < HEADS; ++o) part[o * a.Hp + h] = gw[o];
+    part[8 * a.Hp + h] = gb2p;
+    part[9 * a.Hp + h] = gb2v;
   }
 }
 
@@ -593,11 +635,8 @@ struct Packed {
   float *w1p, *b1, *w2, *w2t, *b2, *w3, *b3, *log_std;  // [2][Hp][64], [2][Hp], [2][Hp][Hp], [2][Hp][Hp], [2][Hp], [8][Hp], [8], [8]
 };
 
-// flat SB3 vector -> kernel-format weights (zero padding pre-set once at creation)
-__global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ p, const ParamLayout L, const Packed k) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= L.total) return;
-  const float v = p[i];
+// flat SB3 vector element i -> its place(s) in the kernel-format weights (zero padding pre-set once at creation)
+__device__ __forceinline__ void pack_one(int64_t i, float v, const ParamLayout& L, const Packed& k) {
   const int H = L.H, Hp = L.Hp;
   if (i < L.p_w1) {
     k.log_std[i] = v;
@@ -635,6 +674,95 @@ __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ p, 
   }
 }
 
+__global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ p, const ParamLayout L, const Packed k) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < L.total) pack_one(i, p[i], L, k);
+}
+
+// Gradient finalisation: every producer kernel (TN GEMMs, backward-GEMM epilogue, head kernel) wrote per-workgroup
+// partials with plain stores; this kernel sums them in a fixed order into the flat SB3-order gradient, adds the entropy
+// term, accumulates the loss statistics and (fused) the per-block sum of squares for clip_grad_norm_.  No float atomics
+// touch a gradient anywhere, so results are bitwise reproducible run to run.
+struct FinalizeArgs {
+  ParamLayout L;
+  const float* slab2; int64_t s2_ld, s2_net, s2_chunk; int s2_n;   // dW2 partials [chunk][net][Hp][Hp]
+  const float* slab1; int64_t s1_ld, s1_net, s1_chunk; int s1_n;   // dW1 partials [chunk][net][Hp][64]
+  const float* bslab; int64_t b_net, b_tile; int b_n;              // db1 partials [row tile][net][Hp]
+  const float* hpart; int64_t h_stride; int h_n;                   // head partials [block][10 Hp + 18]
+  float ent_coef, inv_count;
+  const float* log_std;
+  float* grad; float* stats; double* sumsq;
+};
+
+template <int UNROLL>
+__device__ __forceinline__ float sum_strided(const float* __restrict__ p, int64_t stride, int n) {
+  float s = 0.f;
+  int c = 0;
+  for (; c + UNROLL <= n; c += UNROLL) {
+    float v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) v[u] = p[(int64_t)(c + u) * stride];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) s += v[u];
+  }
+  for (; c < n; ++c) s += p[(int64_t)c * stride];
+  return s;
+}
+
+__global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a) {
+  const ParamLayout& L = a.L;
+  const int H = L.H, Hp = L.Hp;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float gval = 0.f;
+  if (i < L.total) {
+    if (i < L.p_w1) {
+      gval = sum_strided<8>(a.hpart + 10 * Hp + 8 + i, a.h_stride, a.h_n) - a.ent_coef;  // d(-ent_coef * sum log_std)
+    } else if (i < L.p_b1 || (i >= L.v_w1 && i < L.v_b1)) {
+      const int net = i >= L.v_w1;
+      const int64_t e = i - (net ? L.v_w1 : L.p_w1);
+      gval = sum_strided<8>(a.slab1 + net * a.s1_net + (e / IN) * a.s1_ld + e % IN, a.s1_chunk, a.s1_n);
+    } else if (i < L.p_w2 || (i >= L.v_b1 && i < L.v_w2)) {
+      const int net = i >= L.v_b1;
+      gval = sum_strided<8>(a.bslab + net * a.b_net + (i - (net ? L.v_b1 : L.p_b1)), a.b_tile, a.b_n);
+    } else if (i < L.p_b2 || (i >= L.v_w2 && i < L.v_b2)) {
+      const int net = i >= L.v_w2;
+      const int64_t e = i - (net ? L.v_w2 : L.p_w2);
+      gval = sum_strided<8>(a.slab2 + net * a.s2_net + (e / H) * a.s2_ld + e % H, a.s2_chunk, a.s2_n);
+    } else if (i < L.v_w1) {
+      gval = sum_strided<8>(a.hpart + 8 * Hp + (i - L.p_b2), a.h_stride, a.h_n);
+    } else if (i < L.a_w) {
+      gval = sum_strided<8>(a.hpart + 9 * Hp + (i - L.v_b2), a.h_stride, a.h_n);
+    } else if (i < L.a_b) {
+      const int64_t e = i - L.a_w;
+      gval = sum_strided<8>(a.hpart + (e / H) * Hp + e % H, a.h_stride, a.h_n);
+    } else if (i < L.c_w) {
+      gval = sum_strided<8>(a.hpart + 10 * Hp + (i - L.a_b), a.h_stride, a.h_n);
+    } else if (i < L.c_b) {
+      gval = sum_strided<8>(a.hpart + 7 * Hp + (i - L.c_w), a.h_stride, a.h_n);
+    } else {
+      gval = sum_strided<8>(a.hpart + 10 * Hp + 7, a.h_stride, a.h_n);
+    }
+    a.grad[i] = gval;
+  }
+  if (a.stats && blockIdx.x == 0 && threadIdx.x < 3) {  // policy loss, value loss, approx kl (means over the minibatch)
+    const float v = sum_strided<8>(a.hpart + 10 * Hp + 15 + threadIdx.x, a.h_stride, a.h_n) * a.inv_count;
+    a.stats[threadIdx.x == 2 ? 3 : threadIdx.x] += v;  // single writer
+  }
+  if (a.stats && blockIdx.x == 0 && threadIdx.x == 3) {  // entropy of the state-independent diagonal Gaussian
+    float ent = 0.f;
+    for (int k = 0; k < ACT; ++k) ent += 0.5f + LOG_SQRT_2PI + a.log_std[k];
+    a.stats[2] += ent;
+  }
+  __shared__ double sq[256];
+  sq[threadIdx.x] = (double)gval * (double)gval;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) sq[threadIdx.x] += sq[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.sumsq[blockIdx.x] = sq[0];
+}
+
 __global__ void __launch_bounds__(256) sumsq_partials_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ partials) {
   __shared__ double s[256];
   double a = 0.0;
@@ -649,9 +777,11 @@ __global__ void __launch_bounds__(256) sumsq_partials_kernel(const float* __rest
 }
 
 // torch.nn.utils.clip_grad_norm_ (coef = max_norm / (norm + 1e-6), clamped to 1) + torch.optim.Adam
-__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+// The same pass repacks the updated element into the kernel-format weights and (zero_grad) clears the gradient, so the
+// next minibatch's atomic accumulation starts from zero without a memset launch.
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, const double* __restrict__ partials, int n_partials, float lr, float eps, float max_norm,
-                                                   float bc1, float bc2_sqrt) {
+                                                   float bc1, float bc2_sqrt, const ParamLayout L, const Packed k, int zero_grad) {
   __shared__ float scale_s;
   double s = 0.0;
   if (threadIdx.x < 64) {
@@ -671,7 +801,10 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
   m[i] = mi;
   v[i] = vi;
   const float denom = sqrtf(vi) / bc2_sqrt + eps;
-  p[i] = p[i] - (lr / bc1) * (mi / denom);
+  const float pn = p[i] - (lr / bc1) * (mi / denom);
+  p[i] = pn;
+  pack_one(i, pn, L, k);
+  if (zero_grad) g[i] = 0.f;
 }
 
 }  // namespace
@@ -686,6 +819,12 @@ struct kp1_mlp {
   float* dz2 = nullptr;
   float* dz1 = nullptr;
   double* partials = nullptr;  // [512]
+  float* slab = nullptr;       // [64 chunks][2 nets][Hp][Hp] partial dW2
+  float* slab1 = nullptr;      // [64 chunks][2 nets][Hp][64] partial dW1
+  float* bslab = nullptr;      // [max_batch/64 row tiles][2 nets][Hp] partial db1
+  float* hpart = nullptr;      // [max_batch/32 blocks][10 Hp + 32] head partials
+  int n_finalize_blocks = 0;   // sum-of-squares partials written by the last grad_finalize_kernel
+  int last_s2_n = 0, last_s1_n = 0;
   std::vector<void*> allocs;
 };
 
@@ -694,13 +833,13 @@ namespace {
 constexpr int N_PARTIALS = 128;
 
 // rows of the batch each TN workgroup reduces: aim at ~256 workgroups (one per CU) for the H x H gradient
-int tn_chunk_rows(int n, int Hp) {
-  const int tiles = (Hp / 64) * (Hp / 64) * 2;
+int tn_chunk_rows(int n, int tiles) {
   int chunks = (256 + tiles - 1) / tiles;
+  if (chunks > 64) chunks = 64;     // slab capacity (kp1_mlp_create)
   if (chunks < 1) chunks = 1;
   int rows = (n + chunks - 1) / chunks;
-  rows = (rows + 127) / 128 * 128;  // whole 128-row stages
-  return rows < 128 ? 128 : rows;
+  rows = (rows + 63) / 64 * 64;     // whole 64-row stages
+  return rows < 64 ? 64 : rows;
 }
 
 int mlp_check_device(const kp1_mlp* m) {
@@ -708,37 +847,30 @@ int mlp_check_device(const kp1_mlp* m) {
   return KP1_OK;
 }
 
-constexpr size_t TN_LDS_BYTES = sizeof(float) * 2 * 2 * 128 * (64 + 4);
+constexpr size_t TN_LDS_BYTES = sizeof(float) * 2 * 2 * 64 * (128 + 4);
+
+template <int BN, int EPI, int K>
+int launch_nt_inst(const GemmNT& g, hipStream_t stream) {
+  const size_t bytes = sizeof(float) * (64 * (size_t)(K + 4) + 2 * (size_t)BN * LDT);
+  HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel<BN, EPI, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  hipLaunchKernelGGL((gemm_nt_kernel<BN, EPI, K>), dim3((g.M + 63) / 64, g.N / BN, 2), dim3(256), bytes, stream, g);
+  return KP1_OK;
+}
 
 template <int EPI>
 int launch_nt(const GemmNT& g, hipStream_t stream) {
+  if (g.N % 128 != 0) return fail(KP1_ERR_INVALID, "gemm_nt needs N % 128 == 0");
   // 256-column workgroups (A read once per row block) when that still fills the chip, else 128-column ones
   const int row_tiles = (g.M + 63) / 64;
   const bool wide = (g.N % 256 == 0) && row_tiles * 2 >= 200;
-  const size_t lds_a = sizeof(float) * 64 * (size_t)(g.K + 4);
-  if (wide) {
-    const size_t bytes = lds_a + sizeof(float) * 2 * 256 * LDT;
-    HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel<256, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL((gemm_nt_kernel<256, EPI>), dim3(row_tiles, g.N / 256, 2), dim3(256), bytes, stream, g);
-  } else {
-    const size_t bytes = lds_a + sizeof(float) * 2 * 128 * LDT;
-    HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel<128, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL((gemm_nt_kernel<128, EPI>), dim3(row_tiles, g.N / 128, 2), dim3(256), bytes, stream, g);
-  }
-  return KP1_OK;
+  if (g.K == 64) return wide ? launch_nt_inst<256, EPI, 64>(g, stream) : launch_nt_inst<128, EPI, 64>(g, stream);
+  if (g.K == 128) return wide ? launch_nt_inst<256, EPI, 128>(g, stream) : launch_nt_inst<128, EPI, 128>(g, stream);
+  if (g.K == 256) return wide ? launch_nt_inst<256, EPI, 256>(g, stream) : launch_nt_inst<128, EPI, 256>(g, stream);
+  return fail(KP1_ERR_UNSUPPORTED, "gemm_nt is instantiated for K in {64, 128, 256}");
 }
 
-int launch_tn(const GemmTN& t, int n_o_tiles, hipStream_t stream) {
-  const dim3 grid((t.B + t.chunk - 1) / t.chunk, n_o_tiles * t.n_i_tiles, 2);
-  if (t.gatherX) {
-    HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
-    hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), TN_LDS_BYTES, stream, t);
-  } else {
-    HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
-    hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), TN_LDS_BYTES, stream, t);
-  }
-  return KP1_OK;
-}
+// dW (both nets) = D^T X over n rows: split-B partial tiles into m->slab, then the fixed-order reduce into G
+int launch_tn(kp1_mlp* m, GemmTN t, int n_o_tiles, int slab_cols, float* slab, int* n_chunks_out, hipStream_t stream);
 
 // forward layers 1 and 2 for n rows (both nets): h1, h2 filled
 int launch_forward_layers(kp1_mlp* m, const float* obs, int obs_stride, const int64_t* idx, int n, hipStream_t stream) {
@@ -766,13 +898,36 @@ int launch_forward_layers(kp1_mlp* m, const float* obs, int obs_stride, const in
 
 }  // namespace
 
+namespace {
+int launch_tn(kp1_mlp* m, GemmTN t, int n_o_tiles, int slab_cols, float* slab, int* n_chunks_out, hipStream_t stream) {
+  const int Hp = m->Hp;
+  const int n_chunks = (t.B + t.chunk - 1) / t.chunk;
+  if (n_chunks > 64) return fail(KP1_ERR_INVALID, "too many batch chunks for the partial-gradient slab");
+  t.slab = slab;
+  t.slab_ld = slab_cols;
+  t.slab_net_stride = (int64_t)Hp * slab_cols;
+  t.slab_chunk_stride = 2 * t.slab_net_stride;
+  const dim3 grid(n_chunks, n_o_tiles * t.n_i_tiles, 2);
+  if (t.gatherX) {
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), TN_LDS_BYTES, stream, t);
+  } else {
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TN_LDS_BYTES));
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), TN_LDS_BYTES, stream, t);
+  }
+  if (n_chunks_out) *n_chunks_out = n_chunks;
+  return KP1_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int64_t kp1_mlp_num_params(int32_t hidden) { return hidden > 0 ? make_layout(hidden).total : 0; }
 
 int kp1_mlp_create(int32_t device, int32_t hidden, int32_t max_batch, kp1_mlp** out) {
   if (!out || hidden <= 0 || hidden > 1024 || max_batch <= 0) return fail(KP1_ERR_INVALID, "bad argument to kp1_mlp_create");
-  if (hidden % 128 != 0) return fail(KP1_ERR_UNSUPPORTED, "hidden must be a multiple of 128 (the 128-wide MFMA column tile); 2x256 is BASELINE config 2");
+  if (hidden != 128 && hidden != 256)
+    return fail(KP1_ERR_UNSUPPORTED, "hidden must be 128 or 256 (MFMA kernels are instantiated for these widths; 2x256 is BASELINE config 2)");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(KP1_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
   if (device < 0 || device >= count) return fail(KP1_ERR_INVALID, "device index out of range");
@@ -803,7 +958,11 @@ int kp1_mlp_create(int32_t device, int32_t hidden, int32_t max_batch, kp1_mlp** 
   MLP_ALLOC(m->h2, 2 * mb * Hp);
   MLP_ALLOC(m->dz2, 2 * mb * Hp);
   MLP_ALLOC(m->dz1, 2 * mb * Hp);
-  MLP_ALLOC(m->partials, 2 * N_PARTIALS);
+  MLP_ALLOC(m->partials, 2 * N_PARTIALS + 2048);
+  MLP_ALLOC(m->slab, (int64_t)64 * 2 * Hp * Hp);
+  MLP_ALLOC(m->slab1, (int64_t)64 * 2 * Hp * INP);
+  MLP_ALLOC(m->bslab, (mb / 64) * 2 * Hp);
+  MLP_ALLOC(m->hpart, (mb / 32) * (10 * Hp + 32));
 #undef MLP_ALLOC
   if (rc != KP1_OK) {
     kp1_mlp_destroy(m);
@@ -852,7 +1011,7 @@ int kp1_mlp_forward(kp1_mlp* m, const float* obs, int32_t obs_stride, int32_t n,
 int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const int64_t* idx, int32_t n, const float* actions,
                       const float* old_log_prob, const float* advantages, const float* returns, float adv_mean, float adv_inv_std,
                       const float* adv_stats_dev, float clip_range, float ent_coef, float vf_coef, float inv_count, float* grad_out,
-                      float* stats_out, void* stream_) {
+                      float* stats_out, int32_t grad_is_zero, void* stream_) {
   if (!m || !obs || !actions || !old_log_prob || !advantages || !returns || !grad_out) return fail(KP1_ERR_INVALID, "NULL argument");
   if (n <= 0 || n > m->max_batch) return fail(KP1_ERR_INVALID, "n exceeds the workspace max_batch");
   if (obs_stride != IN && obs_stride != INP) return fail(KP1_ERR_INVALID, "obs_stride must be 56 or 64");
@@ -862,7 +1021,7 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   const int Hp = m->Hp, H = m->H;
   const int64_t act_stride = (int64_t)m->max_batch * Hp;
   const ParamLayout& L = m->L;
-  HIP_TRY(hipMemsetAsync(grad_out, 0, sizeof(float) * (size_t)L.total, stream));
+  (void)grad_is_zero;  // every gradient element is written (not accumulated) by grad_finalize_kernel
   rc = launch_forward_layers(m, obs, obs_stride, idx, n, stream);
   if (rc != KP1_OK) return rc;
 
@@ -878,10 +1037,8 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   if (a.adv_mode == 1) hipLaunchKernelGGL(adv_partials_kernel, dim3(N_PARTIALS), dim3(256), 0, stream, advantages, idx, n, m->partials);
   a.clip_range = clip_range; a.ent_coef = ent_coef; a.vf_coef = vf_coef; a.inv_count = inv_count;
   a.dz2 = m->dz2;
-  a.g_action_w = grad_out + L.a_w; a.g_action_b = grad_out + L.a_b; a.g_value_w = grad_out + L.c_w; a.g_value_b = grad_out + L.c_b;
-  a.g_log_std = grad_out + L.log_std; a.g_b2p = grad_out + L.p_b2; a.g_b2v = grad_out + L.v_b2;
-  a.stats = stats_out;
-  hipLaunchKernelGGL(head_train_kernel, dim3((n + HEAD_ROWS - 1) / HEAD_ROWS), dim3(256), sizeof(float) * (HEADS * Hp + HEAD_ROWS * 8 + 8), stream, a);
+  a.hpart = m->hpart; a.hpart_stride = 10 * Hp + 32;
+  hipLaunchKernelGGL(head_train_kernel, dim3((n + HEAD_ROWS - 1) / HEAD_ROWS), dim3(256), sizeof(float) * (HEADS * Hp + HEAD_ROWS * 8 + 24 + 2 * HEAD_ROWS * (Hp + 4)), stream, a);
 
   // dZ1 = (dZ2 W2) * (1 - h1^2), bias-1 gradient = column sums of dZ1 (into a padded scratch, copied below by the TN stage)
   GemmNT g{};
@@ -890,34 +1047,40 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   g.bias = nullptr; g.strideBias = 0;
   g.C = m->dz1; g.ldc = Hp; g.strideC = act_stride;
   g.aux = m->h1; g.strideAux = act_stride;
-  g.colsum = nullptr; g.strideColsum = 0;
+  g.colsum = m->bslab; g.strideColsum = Hp;  // per-row-block bias-gradient partials
   g.M = n; g.N = Hp; g.K = Hp; g.Kreal = Hp;
-  // b1 gradients live at different flat offsets for the two nets; colsum stride expresses that when H == Hp
-  if (H == Hp) {
-    g.colsum = grad_out + L.p_b1;
-    g.strideColsum = L.v_b1 - L.p_b1;
-  }
   rc = launch_nt<EPI_DTANH>(g, stream);
   if (rc != KP1_OK) return rc;
 
   // weight gradients (split over the batch axis)
   GemmTN t{};
   t.B = n;
-  t.chunk = tn_chunk_rows(n, Hp);
+  t.chunk = tn_chunk_rows(n, (Hp / 128) * (Hp / 128) * 2);
   // dW2[o][i] = sum_b dZ2[b][o] h1[b][i]
   t.D = m->dz2; t.ldd = Hp; t.strideD = act_stride;
   t.X = m->h1; t.ldx = Hp; t.strideX = act_stride; t.gatherX = nullptr;
-  t.G = grad_out + L.p_w2; t.ldg = H; t.strideG = L.v_w2 - L.p_w2;
-  t.Mreal = H; t.Nreal = H; t.Nload = Hp; t.n_i_tiles = Hp / 64;
-  rc = launch_tn(t, Hp / 64, stream);
+  t.Nload = Hp; t.n_i_tiles = Hp / 128;
+  int s2_n = 0, s1_n = 0;
+  rc = launch_tn(m, t, Hp / 128, Hp, m->slab, &s2_n, stream);
   if (rc != KP1_OK) return rc;
   // dW1[o][i] = sum_b dZ1[b][o] x[b][i]   (i < 56)
   t.D = m->dz1;
   t.X = obs; t.ldx = obs_stride; t.strideX = 0; t.gatherX = idx;
-  t.G = grad_out + L.p_w1; t.ldg = IN; t.strideG = L.v_w1 - L.p_w1;
-  t.Nreal = IN; t.Nload = obs_stride >= INP ? INP : IN; t.n_i_tiles = 1;
-  rc = launch_tn(t, Hp / 64, stream);
+  t.Nload = obs_stride >= INP ? INP : IN; t.n_i_tiles = 1;
+  t.chunk = tn_chunk_rows(n, (Hp / 128) * 2);  // few tiles: more, shorter batch chunks keep the CUs busy
+  rc = launch_tn(m, t, Hp / 128, INP, m->slab1, &s1_n, stream);
   if (rc != KP1_OK) return rc;
+  FinalizeArgs f{};
+  f.L = L;
+  f.slab2 = m->slab; f.s2_ld = Hp; f.s2_net = (int64_t)Hp * Hp; f.s2_chunk = 2 * f.s2_net; f.s2_n = s2_n;
+  f.slab1 = m->slab1; f.s1_ld = INP; f.s1_net = (int64_t)Hp * INP; f.s1_chunk = 2 * f.s1_net; f.s1_n = s1_n;
+  f.bslab = m->bslab; f.b_net = Hp; f.b_tile = 2 * Hp; f.b_n = (n + 63) / 64;
+  f.hpart = m->hpart; f.h_stride = 10 * Hp + 32; f.h_n = (n + HEAD_ROWS - 1) / HEAD_ROWS;
+  f.ent_coef = ent_coef; f.inv_count = inv_count; f.log_std = m->k.log_std;
+  f.grad = grad_out; f.stats = stats_out; f.sumsq = m->partials + 2 * N_PARTIALS;
+  m->n_finalize_blocks = (int)((L.total + 255) / 256);
+  if (m->n_finalize_blocks > 2048) return fail(KP1_ERR_INVALID, "parameter vector too large for the sum-of-squares partial buffer");
+  hipLaunchKernelGGL(grad_finalize_kernel, dim3(m->n_finalize_blocks), dim3(256), 0, stream, f);
   HIP_TRY(hipGetLastError());
   return KP1_OK;
 }
@@ -952,11 +1115,10 @@ int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32
         if (launch_nt<EPI_DTANH>(g, stream) != KP1_OK) return KP1_ERR_NO_DEVICE;
       } else if (which == 2) {
         GemmTN t{};
-        t.B = n; t.chunk = tn_chunk_rows(n, Hp);
+        t.B = n; t.chunk = tn_chunk_rows(n, (Hp / 128) * (Hp / 128) * 2);
         t.D = m->dz2; t.ldd = Hp; t.strideD = act_stride; t.X = m->h1; t.ldx = Hp; t.strideX = act_stride;
-        t.G = m->dz1; t.ldg = Hp; t.strideG = act_stride;  // scratch target (dz1 is rewritten by kernel 1 anyway)
-        t.Mreal = Hp; t.Nreal = Hp; t.Nload = Hp; t.n_i_tiles = Hp / 64;
-        if (launch_tn(t, Hp / 64, stream) != KP1_OK) return KP1_ERR_NO_DEVICE;
+        t.Nload = Hp; t.n_i_tiles = Hp / 128;
+        if (launch_tn(m, t, Hp / 128, Hp, m->slab, nullptr, stream) != KP1_OK) return KP1_ERR_NO_DEVICE;
       } else {
         g.A = obs; g.lda = obs_stride; g.strideA = 0; g.W = m->k.w1p; g.strideW = (int64_t)Hp * INP; g.bias = m->k.b1; g.strideBias = Hp;
         g.C = m->h1; g.K = INP; g.Kreal = obs_stride >= INP ? INP : IN;
@@ -984,19 +1146,24 @@ int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32
   return KP1_OK;
 }
 
-int kp1_mlp_adam_step(kp1_mlp* m, float* params, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float eps, float max_grad_norm,
-                      int32_t step, void* stream_) {
+int kp1_mlp_adam_step(kp1_mlp* m, float* params, float* grad, float* exp_avg, float* exp_avg_sq, float lr, float eps, float max_grad_norm,
+                      int32_t step, int32_t zero_grad, void* stream_) {
   if (!m || !params || !grad || !exp_avg || !exp_avg_sq || step <= 0) return fail(KP1_ERR_INVALID, "bad argument to kp1_mlp_adam_step");
   int rc = mlp_check_device(m);
   if (rc != KP1_OK) return rc;
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t n = m->L.total;
-  hipLaunchKernelGGL(sumsq_partials_kernel, dim3(N_PARTIALS), dim3(256), 0, stream, grad, n, m->partials + N_PARTIALS);
+  // zero_grad & 2: the caller did not touch grad since kp1_mlp_loss_grad (single GPU), so the sum-of-squares partials
+  // the finalize kernel left are the norm of exactly this gradient and the extra reduction launch is skipped
+  const bool fused_norm = (zero_grad & 2) && m->n_finalize_blocks > 0;
+  const double* norm_partials = fused_norm ? m->partials + 2 * N_PARTIALS : m->partials + N_PARTIALS;
+  const int n_norm_partials = fused_norm ? m->n_finalize_blocks : N_PARTIALS;
+  if (!fused_norm) hipLaunchKernelGGL(sumsq_partials_kernel, dim3(N_PARTIALS), dim3(256), 0, stream, grad, n, m->partials + N_PARTIALS);
+  zero_grad = 0;  // gradients are overwritten by the next finalize; nothing to clear
   const float bc1 = 1.f - std::pow(0.9f, (float)step);
   const float bc2 = 1.f - std::pow(0.999f, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, params, grad, exp_avg, exp_avg_sq, n,
-                     m->partials + N_PARTIALS, N_PARTIALS, lr, eps, max_grad_norm, bc1, std::sqrt(bc2));
-  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, params, m->L, m->k);
+                     norm_partials, n_norm_partials, lr, eps, max_grad_norm, bc1, std::sqrt(bc2), m->L, m->k, zero_grad);
   HIP_TRY(hipGetLastError());
   return KP1_OK;
 }

@@ -25,8 +25,8 @@ class MlpKernels:
         L.kp1_mlp_num_params.restype = C.c_int64
         L.kp1_mlp_pack_weights.argtypes = [vp, vp, vp]
         L.kp1_mlp_forward.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
-        L.kp1_mlp_loss_grad.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, f32, f32, vp, f32, f32, f32, f32, vp, vp, vp]
-        L.kp1_mlp_adam_step.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, i32, vp]
+        L.kp1_mlp_loss_grad.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, f32, f32, vp, f32, f32, f32, f32, vp, vp, i32, vp]
+        L.kp1_mlp_adam_step.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, i32, i32, vp]
         L.kp1_mlp_time_kernels.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
         self.hidden = hidden
         self.device = device
@@ -64,14 +64,18 @@ class MlpKernels:
 
     def loss_grad(self, obs: torch.Tensor, idx: torch.Tensor | None, n: int, actions, old_logp, adv, ret, *, clip_range: float, ent_coef: float,
                   vf_coef: float, inv_count: float, grad_out: torch.Tensor, stats_out: torch.Tensor | None, adv_stats: torch.Tensor | None = None,
-                  normalize: bool = True) -> None:
+                  normalize: bool = True, grad_is_zero: bool = False) -> None:
         assert obs.is_contiguous() and grad_out.numel() == self.num_params
         inv_std = 0.0 if normalize else -1.0
         native.check(self.L.kp1_mlp_loss_grad(self._h, _p(obs), obs.shape[-1], _p(idx), n, _p(actions), _p(old_logp), _p(adv), _p(ret), 0.0, inv_std,
-                                              _p(adv_stats), clip_range, ent_coef, vf_coef, inv_count, _p(grad_out), _p(stats_out), self._stream()))
+                                              _p(adv_stats), clip_range, ent_coef, vf_coef, inv_count, _p(grad_out), _p(stats_out), int(grad_is_zero), self._stream()))
 
-    def adam_step(self, params, grad, exp_avg, exp_avg_sq, *, lr: float, eps: float, max_grad_norm: float, step: int) -> None:
-        native.check(self.L.kp1_mlp_adam_step(self._h, _p(params), _p(grad), _p(exp_avg), _p(exp_avg_sq), lr, eps, max_grad_norm, step, self._stream()))
+    def adam_step(self, params, grad, exp_avg, exp_avg_sq, *, lr: float, eps: float, max_grad_norm: float, step: int,
+                  fused_norm: bool = False) -> None:
+        """fused_norm: grad is exactly what the last loss_grad call wrote (no all-reduce in between), so the sum-of-squares
+        partials its finalize kernel left are reused and the separate norm reduction launch is skipped."""
+        native.check(self.L.kp1_mlp_adam_step(self._h, _p(params), _p(grad), _p(exp_avg), _p(exp_avg_sq), lr, eps, max_grad_norm, step,
+                                              2 if fused_norm else 0, self._stream()))
 
     def time_kernels(self, obs: torch.Tensor, n: int, iters: int = 20) -> dict[str, dict[str, float]]:
         """HIP-event timings of the MFMA GEMM kernels at minibatch size n (bench.py roofline block)."""

@@ -335,7 +335,7 @@ class PPO:
         self.dist.all_reduce_sum(self.grad)
         self.adam_t += 1
         self._mlp.adam_step(self.policy.flat, self.grad, self.adam_m, self.adam_v, lr=cfg.learning_rate, eps=cfg.adam_eps,
-                            max_grad_norm=cfg.max_grad_norm, step=self.adam_t)
+                            max_grad_norm=cfg.max_grad_norm, step=self.adam_t, fused_norm=not self.dist.enabled)
 
     def _normalize_adv(self, adv: torch.Tensor) -> torch.Tensor:
         if not self.cfg.normalize_advantage or adv.numel() * self.dist.world_size <= 1:
