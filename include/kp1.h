@@ -441,6 +441,8 @@ int kp1_config_default(kp1_config* cfg);
 int kp1_create(const kp1_config* cfg, int32_t n_envs, int32_t device, int32_t real_type,
                uint64_t seed0, uint64_t first_env_id, void* stream, kp1_env** out);
 int kp1_destroy(kp1_env* env);
+/* change the HIP stream later launches of this handle are ordered on (e.g. a stream under hipGraph capture) */
+int kp1_set_stream(kp1_env* env, void* stream);
 int kp1_num_envs(const kp1_env* env);
 
 /* set_curriculum_stage / get_curriculum_stage (all envs, like VecEnv.env_method); :446-452 */

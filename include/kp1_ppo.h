@@ -105,7 +105,8 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
                       float* stats_out, int32_t grad_is_zero, void* stream);
 
 /* clip_grad_norm_(max_norm) + Adam(beta 0.9/0.999, eps) step on the flat vectors; the same pass repacks the kernel-format
- * weights.  step = 1-based Adam step count.  flags bit 1 (value 2): grad is untouched since the kp1_mlp_loss_grad call that
+ * weights.  step = 1-based Adam step count, or <= 0 to use the device-resident counter that every kp1_mlp_loss_grad call
+ * increments (needed when the call sequence is replayed from a hipGraph).  flags bit 1 (value 2): grad is untouched since the kp1_mlp_loss_grad call that
  * produced it (no all-reduce in between), so the norm partials that call left are reused instead of a reduction launch. */
 int kp1_mlp_adam_step(kp1_mlp* m, float* params, float* grad, float* exp_avg, float* exp_avg_sq, float lr, float eps,
                       float max_grad_norm, int32_t step, int32_t flags, void* stream);

@@ -983,6 +983,11 @@ int kp1_bind_stage_ptr(kp1_env* e, const int32_t* stage_dev) {
   e->stage_ptr = stage_dev;
   return KP1_OK;
 }
+int kp1_set_stream(kp1_env* e, void* stream) {
+  if (!e) return fail(KP1_ERR_INVALID, "env is NULL");
+  e->stream = (hipStream_t)stream;
+  return KP1_OK;
+}
 int kp1_set_obs_stride(kp1_env* e, int32_t stride) {
   if (!e) return fail(KP1_ERR_INVALID, "env is NULL");
   if (stride != KP1_OBS_DIM && stride != 64) return fail(KP1_ERR_INVALID, "obs stride must be 56 or 64");

@@ -692,6 +692,7 @@ struct FinalizeArgs {
   float ent_coef, inv_count;
   const float* log_std;
   float* grad; float* stats; double* sumsq;
+  int* step_counter;  // Adam step count kept on the device (hipGraph replays cannot change a scalar kernel argument)
 };
 
 template <int UNROLL>
@@ -716,38 +717,39 @@ __global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a
   float gval = 0.f;
   if (i < L.total) {
     if (i < L.p_w1) {
-      gval = sum_strided<8>(a.hpart + 10 * Hp + 8 + i, a.h_stride, a.h_n) - a.ent_coef;  // d(-ent_coef * sum log_std)
+      gval = sum_strided<32>(a.hpart + 10 * Hp + 8 + i, a.h_stride, a.h_n) - a.ent_coef;  // d(-ent_coef * sum log_std)
     } else if (i < L.p_b1 || (i >= L.v_w1 && i < L.v_b1)) {
       const int net = i >= L.v_w1;
       const int64_t e = i - (net ? L.v_w1 : L.p_w1);
-      gval = sum_strided<8>(a.slab1 + net * a.s1_net + (e / IN) * a.s1_ld + e % IN, a.s1_chunk, a.s1_n);
+      gval = sum_strided<32>(a.slab1 + net * a.s1_net + (e / IN) * a.s1_ld + e % IN, a.s1_chunk, a.s1_n);
     } else if (i < L.p_w2 || (i >= L.v_b1 && i < L.v_w2)) {
       const int net = i >= L.v_b1;
-      gval = sum_strided<8>(a.bslab + net * a.b_net + (i - (net ? L.v_b1 : L.p_b1)), a.b_tile, a.b_n);
+      gval = sum_strided<32>(a.bslab + net * a.b_net + (i - (net ? L.v_b1 : L.p_b1)), a.b_tile, a.b_n);
     } else if (i < L.p_b2 || (i >= L.v_w2 && i < L.v_b2)) {
       const int net = i >= L.v_w2;
       const int64_t e = i - (net ? L.v_w2 : L.p_w2);
-      gval = sum_strided<8>(a.slab2 + net * a.s2_net + (e / H) * a.s2_ld + e % H, a.s2_chunk, a.s2_n);
+      gval = sum_strided<16>(a.slab2 + net * a.s2_net + (e / H) * a.s2_ld + e % H, a.s2_chunk, a.s2_n);
     } else if (i < L.v_w1) {
-      gval = sum_strided<8>(a.hpart + 8 * Hp + (i - L.p_b2), a.h_stride, a.h_n);
+      gval = sum_strided<32>(a.hpart + 8 * Hp + (i - L.p_b2), a.h_stride, a.h_n);
     } else if (i < L.a_w) {
-      gval = sum_strided<8>(a.hpart + 9 * Hp + (i - L.v_b2), a.h_stride, a.h_n);
+      gval = sum_strided<32>(a.hpart + 9 * Hp + (i - L.v_b2), a.h_stride, a.h_n);
     } else if (i < L.a_b) {
       const int64_t e = i - L.a_w;
-      gval = sum_strided<8>(a.hpart + (e / H) * Hp + e % H, a.h_stride, a.h_n);
+      gval = sum_strided<32>(a.hpart + (e / H) * Hp + e % H, a.h_stride, a.h_n);
     } else if (i < L.c_w) {
-      gval = sum_strided<8>(a.hpart + 10 * Hp + (i - L.a_b), a.h_stride, a.h_n);
+      gval = sum_strided<32>(a.hpart + 10 * Hp + (i - L.a_b), a.h_stride, a.h_n);
     } else if (i < L.c_b) {
-      gval = sum_strided<8>(a.hpart + 7 * Hp + (i - L.c_w), a.h_stride, a.h_n);
+      gval = sum_strided<32>(a.hpart + 7 * Hp + (i - L.c_w), a.h_stride, a.h_n);
     } else {
-      gval = sum_strided<8>(a.hpart + 10 * Hp + 7, a.h_stride, a.h_n);
+      gval = sum_strided<32>(a.hpart + 10 * Hp + 7, a.h_stride, a.h_n);
     }
     a.grad[i] = gval;
   }
   if (a.stats && blockIdx.x == 0 && threadIdx.x < 3) {  // policy loss, value loss, approx kl (means over the minibatch)
-    const float v = sum_strided<8>(a.hpart + 10 * Hp + 15 + threadIdx.x, a.h_stride, a.h_n) * a.inv_count;
+    const float v = sum_strided<32>(a.hpart + 10 * Hp + 15 + threadIdx.x, a.h_stride, a.h_n) * a.inv_count;
     a.stats[threadIdx.x == 2 ? 3 : threadIdx.x] += v;  // single writer
   }
+  if (a.step_counter && blockIdx.x == 0 && threadIdx.x == 4) *a.step_counter += 1;  // read by the adam kernel that follows
   if (a.stats && blockIdx.x == 0 && threadIdx.x == 3) {  // entropy of the state-independent diagonal Gaussian
     float ent = 0.f;
     for (int k = 0; k < ACT; ++k) ent += 0.5f + LOG_SQRT_2PI + a.log_std[k];
@@ -781,8 +783,14 @@ __global__ void __launch_bounds__(256) sumsq_partials_kernel(const float* __rest
 // next minibatch's atomic accumulation starts from zero without a memset launch.
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, const double* __restrict__ partials, int n_partials, float lr, float eps, float max_norm,
-                                                   float bc1, float bc2_sqrt, const ParamLayout L, const Packed k, int zero_grad) {
+                                                   float bc1, float bc2_sqrt, const ParamLayout L, const Packed k, int zero_grad,
+                                                   const int* __restrict__ step_counter) {
   __shared__ float scale_s;
+  if (step_counter) {  // bias corrections from the device-resident step count
+    const float st = (float)*step_counter;
+    bc1 = 1.f - powf(0.9f, st);
+    bc2_sqrt = sqrtf(1.f - powf(0.999f, st));
+  }
   double s = 0.0;
   if (threadIdx.x < 64) {
     for (int k = threadIdx.x; k < n_partials; k += 64) s += partials[k];
@@ -824,6 +832,7 @@ struct kp1_mlp {
   float* bslab = nullptr;      // [max_batch/64 row tiles][2 nets][Hp] partial db1
   float* hpart = nullptr;      // [max_batch/32 blocks][10 Hp + 32] head partials
   int n_finalize_blocks = 0;   // sum-of-squares partials written by the last grad_finalize_kernel
+  int* step_dev = nullptr;     // device Adam step counter
   int last_s2_n = 0, last_s1_n = 0;
   std::vector<void*> allocs;
 };
@@ -961,6 +970,7 @@ int kp1_mlp_create(int32_t device, int32_t hidden, int32_t max_batch, kp1_mlp** 
   MLP_ALLOC(m->partials, 2 * N_PARTIALS + 2048);
   MLP_ALLOC(m->slab, (int64_t)64 * 2 * Hp * Hp);
   MLP_ALLOC(m->slab1, (int64_t)64 * 2 * Hp * INP);
+  MLP_ALLOC(m->step_dev, 4);
   MLP_ALLOC(m->bslab, (mb / 64) * 2 * Hp);
   MLP_ALLOC(m->hpart, (mb / 32) * (10 * Hp + 32));
 #undef MLP_ALLOC
@@ -1078,6 +1088,7 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   f.hpart = m->hpart; f.h_stride = 10 * Hp + 32; f.h_n = (n + HEAD_ROWS - 1) / HEAD_ROWS;
   f.ent_coef = ent_coef; f.inv_count = inv_count; f.log_std = m->k.log_std;
   f.grad = grad_out; f.stats = stats_out; f.sumsq = m->partials + 2 * N_PARTIALS;
+  f.step_counter = m->step_dev;
   m->n_finalize_blocks = (int)((L.total + 255) / 256);
   if (m->n_finalize_blocks > 2048) return fail(KP1_ERR_INVALID, "parameter vector too large for the sum-of-squares partial buffer");
   hipLaunchKernelGGL(grad_finalize_kernel, dim3(m->n_finalize_blocks), dim3(256), 0, stream, f);
@@ -1148,7 +1159,7 @@ int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32
 
 int kp1_mlp_adam_step(kp1_mlp* m, float* params, float* grad, float* exp_avg, float* exp_avg_sq, float lr, float eps, float max_grad_norm,
                       int32_t step, int32_t zero_grad, void* stream_) {
-  if (!m || !params || !grad || !exp_avg || !exp_avg_sq || step <= 0) return fail(KP1_ERR_INVALID, "bad argument to kp1_mlp_adam_step");
+  if (!m || !params || !grad || !exp_avg || !exp_avg_sq) return fail(KP1_ERR_INVALID, "bad argument to kp1_mlp_adam_step");
   int rc = mlp_check_device(m);
   if (rc != KP1_OK) return rc;
   hipStream_t stream = (hipStream_t)stream_;
@@ -1160,10 +1171,13 @@ int kp1_mlp_adam_step(kp1_mlp* m, float* params, float* grad, float* exp_avg, fl
   const int n_norm_partials = fused_norm ? m->n_finalize_blocks : N_PARTIALS;
   if (!fused_norm) hipLaunchKernelGGL(sumsq_partials_kernel, dim3(N_PARTIALS), dim3(256), 0, stream, grad, n, m->partials + N_PARTIALS);
   zero_grad = 0;  // gradients are overwritten by the next finalize; nothing to clear
-  const float bc1 = 1.f - std::pow(0.9f, (float)step);
-  const float bc2 = 1.f - std::pow(0.999f, (float)step);
+  // step <= 0: use the device-resident counter that kp1_mlp_loss_grad's finalize kernel increments (graph-replay safe)
+  const int host_step = step > 0 ? step : 1;
+  const float bc1 = 1.f - std::pow(0.9f, (float)host_step);
+  const float bc2 = 1.f - std::pow(0.999f, (float)host_step);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, params, grad, exp_avg, exp_avg_sq, n,
-                     norm_partials, n_norm_partials, lr, eps, max_grad_norm, bc1, std::sqrt(bc2), m->L, m->k, zero_grad);
+                     norm_partials, n_norm_partials, lr, eps, max_grad_norm, bc1, std::sqrt(bc2), m->L, m->k, zero_grad,
+                     step > 0 ? (const int*)nullptr : (const int*)m->step_dev);
   HIP_TRY(hipGetLastError());
   return KP1_OK;
 }

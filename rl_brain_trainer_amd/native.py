@@ -59,6 +59,7 @@ def load() -> C.CDLL:
     L.kp1_config_default.argtypes = [C.POINTER(kcfg.Kp1Config)]
     L.kp1_create.argtypes = [C.POINTER(kcfg.Kp1Config), i32, i32, i32, u64, u64, vp, C.POINTER(vp)]
     L.kp1_destroy.argtypes = [vp]
+    L.kp1_set_stream.argtypes = [vp, vp]
     L.kp1_num_envs.argtypes = [vp]
     L.kp1_set_stage.argtypes = [vp, i32]
     L.kp1_get_stage.argtypes = [vp, C.POINTER(i32)]

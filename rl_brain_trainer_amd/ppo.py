@@ -172,7 +172,7 @@ class Dist:
 
 class PPO:
     def __init__(self, env: ArmKinematicVecEnv, cfg: PPOConfig, *, curriculum: PointCurriculum | None = None,
-                 dist: Dist | None = None, backend: str = "hip") -> None:
+                 dist: Dist | None = None, backend: str = "hip", use_graphs: bool = True) -> None:
         self.env = env
         self.cfg = cfg
         self.device = env.device
@@ -222,6 +222,13 @@ class PPO:
             self.noise = torch.zeros((N, ACT_DIM), dtype=torch.float32, device=dev)
         elif backend != "torch":
             raise ValueError("backend must be 'hip' or 'torch'")
+        # hipGraph replay of the rollout (T x 5 launches) and of one update epoch: single GPU only (no RCCL inside capture)
+        self.use_graphs = bool(use_graphs and backend == "hip" and not self.dist.enabled)
+        self._rollout_graph = None
+        self._epoch_graph = None
+        if self.use_graphs:
+            self.noise_all = torch.zeros((T, N, ACT_DIM), dtype=torch.float32, device=dev)
+            self.perm = torch.zeros(T * N, dtype=torch.int64, device=dev)
 
     # ------------------------------------------------------------------ policy evaluation
     def _forward(self, obs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
@@ -255,7 +262,12 @@ class PPO:
         log_std = self.policy.views["log_std"]
         std = torch.exp(log_std)
         world = self.dist.world_size
-        for t in range(T):
+        if self.use_graphs:
+            self.noise_all.normal_(generator=self.gen)
+            if self._rollout_graph is None:
+                self._capture_rollout()
+            self._rollout_graph.replay()
+        for t in range(0 if not self.use_graphs else T, T):
             if self._mlp is not None:
                 # 3 launches: two MFMA layer GEMMs + the head kernel (heads, sampling, log-prob, clip fused)
                 self.noise.normal_(generator=self.gen)
@@ -286,6 +298,46 @@ class PPO:
                                          C.c_void_p(self.done_buf.data_ptr()), C.c_void_p(last_v.data_ptr()), cfg.gamma, cfg.gae_lambda,
                                          C.c_void_p(self.adv_buf.data_ptr()), C.c_void_p(self.ret_buf.data_ptr()), T, N, C.c_void_p(stream)))
 
+    def _rollout_step_hip(self, t: int) -> None:
+        self._mlp.forward(self.obs_buf[t], noise=self.noise_all[t], value=self.val_buf[t], action=self.act_buf[t],
+                          clipped=self.clip_act, log_prob=self.logp_buf[t])
+        self.env.step_into(self.clip_act, self.obs_buf[t + 1], self.rew_buf[t], self.done_buf[t], self.term_obs_buf[t], True)
+        if self.curriculum is not None:
+            self.curriculum.observe(self.done_buf[t], self.n_envs)
+
+    def _capture_rollout(self) -> None:
+        """Record the T-step rollout (policy forward, env step, curriculum tracker) once; every later rollout is one replay."""
+        T = self.cfg.n_steps
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):  # warm-up on the side stream (sets kernel attributes, loads code objects)
+            self.env.use_current_stream()
+            self._mlp.forward(self.obs_buf[0], noise=self.noise_all[0], value=self.val_buf[0], action=self.act_buf[0],
+                              clipped=self.clip_act, log_prob=self.logp_buf[0])
+            self.env.step_into(self.clip_act, self.obs_buf[1], self.rew_buf[0], self.done_buf[0], self.term_obs_buf[0], True)
+            if self.curriculum is not None:
+                self.curriculum.observe(self.done_buf[0].zero_(), 0)
+            # the warm-up moved every env one step: start the episodes again (one extra reset() draw per env stream)
+            self.env.use_current_stream()
+            self.obs_buf[0].copy_(self.env.reset())
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.env.use_current_stream()
+            for t in range(T):
+                self._rollout_step_hip(t)
+        self.env.use_current_stream()
+        self._rollout_graph = g
+
+    def _capture_epoch(self, obs, act, old_logp, adv, ret, total: int, local_bs: int) -> None:
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.graph(g):
+            for start in range(0, total, local_bs):
+                self._hip_minibatch_step(obs, self.perm[start:start + local_bs], act, old_logp, adv, ret, device_step=True)
+        self._epoch_graph = g
+
     # ------------------------------------------------------------------ update
     def train(self) -> None:
         cfg = self.cfg
@@ -303,6 +355,21 @@ class PPO:
         if self._mlp is not None:
             self.stats_dev.zero_()
         for _epoch in range(cfg.n_epochs):
+            if self.use_graphs:
+                torch.randperm(total, device=self.device, generator=self.gen, out=self.perm)
+                if self._epoch_graph is None:
+                    # one eager epoch first (warm-up + it is a real epoch), then capture for the following ones
+                    if _epoch == 0 and self.adam_t == 0:
+                        for start in range(0, total, local_bs):
+                            self._hip_minibatch_step(obs, self.perm[start:start + local_bs], act, old_logp, adv, ret, device_step=True)
+                            n_updates += 1
+                            self.adam_t += 1
+                        continue
+                    self._capture_epoch(obs, act, old_logp, adv, ret, total, local_bs)
+                self._epoch_graph.replay()
+                n_updates += (total + local_bs - 1) // local_bs
+                self.adam_t += (total + local_bs - 1) // local_bs
+                continue
             perm = torch.randperm(total, device=self.device, generator=self.gen)
             for start in range(0, total, local_bs):
                 idx = perm[start:start + local_bs]
@@ -316,7 +383,7 @@ class PPO:
         self.last_stats = dict(zip(("policy_loss", "value_loss", "entropy", "approx_kl"), (stats / max(n_updates, 1)).tolist()))
         self.last_stats["n_updates"] = n_updates
 
-    def _hip_minibatch_step(self, obs, idx, act, old_logp, adv, ret) -> None:
+    def _hip_minibatch_step(self, obs, idx, act, old_logp, adv, ret, device_step: bool = False) -> None:
         """one optimiser step, all on the device: gathered fwd + loss + bwd (MFMA), flat grad all-reduce, clip + Adam + repack"""
         cfg = self.cfg
         n = int(idx.numel())
@@ -333,9 +400,12 @@ class PPO:
                             inv_count=1.0 / (n * world), grad_out=self.grad, stats_out=self.stats_dev, adv_stats=adv_stats,
                             normalize=cfg.normalize_advantage)
         self.dist.all_reduce_sum(self.grad)
-        self.adam_t += 1
+        if not device_step:
+            self.adam_t += 1
+        # device_step: the Adam step count lives on the device (incremented by loss_grad's finalize kernel) so that the
+        # launch sequence can be replayed from a hipGraph; the host mirror self.adam_t is advanced by the caller
         self._mlp.adam_step(self.policy.flat, self.grad, self.adam_m, self.adam_v, lr=cfg.learning_rate, eps=cfg.adam_eps,
-                            max_grad_norm=cfg.max_grad_norm, step=self.adam_t, fused_norm=not self.dist.enabled)
+                            max_grad_norm=cfg.max_grad_norm, step=0 if device_step else self.adam_t, fused_norm=not self.dist.enabled)
 
     def _normalize_adv(self, adv: torch.Tensor) -> torch.Tensor:
         if not self.cfg.normalize_advantage or adv.numel() * self.dist.world_size <= 1:

@@ -185,6 +185,10 @@ class ArmKinematicVecEnv:
                                      C.c_void_p(self.terminal_obs.data_ptr()), int(auto_reset)))
         return self.obs, self.reward, self.done
 
+    def use_current_stream(self) -> None:
+        """Order this handle's launches on torch's current stream (call inside torch.cuda.graph capture / stream contexts)."""
+        native.check(self.L.kp1_set_stream(self._handle, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
     def step_into(self, actions: torch.Tensor, obs: torch.Tensor, reward: torch.Tensor, done: torch.Tensor,
                   terminal_obs: torch.Tensor | None, auto_reset: bool = True) -> None:
         """Zero-copy variant used by the rollout loop: outputs go straight into caller-owned (rollout) buffers."""
