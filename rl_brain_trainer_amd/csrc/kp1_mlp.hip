@@ -450,6 +450,7 @@ __global__ void __launch_bounds__(256) adv_partials_kernel(const float* __restri
 }
 
 // heads forward + PPO loss gradient + dZ2 for both nets + head weight/bias gradients
+template <int HP>
 __global__ void __launch_bounds__(256) head_train_kernel(const HeadArgs a) {
   // all LDS is one dynamic array (16-B aligned base: head_dot reads float4; guide G17)
   extern __shared__ float smem[];
@@ -461,12 +462,21 @@ __global__ void __launch_bounds__(256) head_train_kernel(const HeadArgs a) {
   float* h2s = adv_ms + 4;                 // [2][HEAD_ROWS][hpitch]: this block's rows of both nets, read from HBM once
   for (int k = threadIdx.x; k < HEADS * a.Hp; k += 256) w3s[k] = a.w3[k];
   {
-    const int q = a.Hp >> 2;               // float4 per row
-    for (int f = threadIdx.x; f < 2 * HEAD_ROWS * q; f += 256) {
-      const int net = f / (HEAD_ROWS * q), rem = f - net * HEAD_ROWS * q, r = rem / q, c4 = rem - r * q;
+    // all loads of this thread in flight before the first LDS store (a load->store loop serialises 16 round trips)
+    constexpr int Q = HP / 4, LOADS = 2 * HEAD_ROWS * Q / 256;
+    f32x4 v[LOADS];
+#pragma unroll
+    for (int j = 0; j < LOADS; ++j) {
+      const int f = threadIdx.x + 256 * j;
+      const int net = f / (HEAD_ROWS * Q), rem = f % (HEAD_ROWS * Q), r = rem / Q, c4 = rem % Q;
       const int grow = min(blockIdx.x * HEAD_ROWS + r, a.n - 1);
-      *reinterpret_cast<float4*>(h2s + (net * HEAD_ROWS + r) * hpitch + 4 * c4) =
-          *reinterpret_cast<const float4*>(a.h2 + net * a.strideH + (int64_t)grow * a.Hp + 4 * c4);
+      v[j] = *reinterpret_cast<const f32x4*>(a.h2 + net * a.strideH + (int64_t)grow * HP + 4 * c4);
+    }
+#pragma unroll
+    for (int j = 0; j < LOADS; ++j) {
+      const int f = threadIdx.x + 256 * j;
+      const int net = f / (HEAD_ROWS * Q), rem = f % (HEAD_ROWS * Q), r = rem / Q, c4 = rem % Q;
+      *reinterpret_cast<f32x4*>(h2s + (net * HEAD_ROWS + r) * hpitch + 4 * c4) = v[j];
     }
   }
   if (threadIdx.x < 20) red[threadIdx.x] = 0.f;
@@ -717,7 +727,7 @@ __global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a
   float gval = 0.f;
   if (i < L.total) {
     if (i < L.p_w1) {
-      gval = sum_strided<32>(a.hpart + 10 * Hp + 8 + i, a.h_stride, a.h_n) - a.ent_coef;  // d(-ent_coef * sum log_std)
+      gval = sum_strided<64>(a.hpart + 10 * Hp + 8 + i, a.h_stride, a.h_n) - a.ent_coef;  // d(-ent_coef * sum log_std)
     } else if (i < L.p_b1 || (i >= L.v_w1 && i < L.v_b1)) {
       const int net = i >= L.v_w1;
       const int64_t e = i - (net ? L.v_w1 : L.p_w1);
@@ -730,23 +740,23 @@ __global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a
       const int64_t e = i - (net ? L.v_w2 : L.p_w2);
       gval = sum_strided<16>(a.slab2 + net * a.s2_net + (e / H) * a.s2_ld + e % H, a.s2_chunk, a.s2_n);
     } else if (i < L.v_w1) {
-      gval = sum_strided<32>(a.hpart + 8 * Hp + (i - L.p_b2), a.h_stride, a.h_n);
+      gval = sum_strided<64>(a.hpart + 8 * Hp + (i - L.p_b2), a.h_stride, a.h_n);
     } else if (i < L.a_w) {
-      gval = sum_strided<32>(a.hpart + 9 * Hp + (i - L.v_b2), a.h_stride, a.h_n);
+      gval = sum_strided<64>(a.hpart + 9 * Hp + (i - L.v_b2), a.h_stride, a.h_n);
     } else if (i < L.a_b) {
       const int64_t e = i - L.a_w;
-      gval = sum_strided<32>(a.hpart + (e / H) * Hp + e % H, a.h_stride, a.h_n);
+      gval = sum_strided<64>(a.hpart + (e / H) * Hp + e % H, a.h_stride, a.h_n);
     } else if (i < L.c_w) {
-      gval = sum_strided<32>(a.hpart + 10 * Hp + (i - L.a_b), a.h_stride, a.h_n);
+      gval = sum_strided<64>(a.hpart + 10 * Hp + (i - L.a_b), a.h_stride, a.h_n);
     } else if (i < L.c_b) {
-      gval = sum_strided<32>(a.hpart + 7 * Hp + (i - L.c_w), a.h_stride, a.h_n);
+      gval = sum_strided<64>(a.hpart + 7 * Hp + (i - L.c_w), a.h_stride, a.h_n);
     } else {
-      gval = sum_strided<32>(a.hpart + 10 * Hp + 7, a.h_stride, a.h_n);
+      gval = sum_strided<64>(a.hpart + 10 * Hp + 7, a.h_stride, a.h_n);
     }
     a.grad[i] = gval;
   }
   if (a.stats && blockIdx.x == 0 && threadIdx.x < 3) {  // policy loss, value loss, approx kl (means over the minibatch)
-    const float v = sum_strided<32>(a.hpart + 10 * Hp + 15 + threadIdx.x, a.h_stride, a.h_n) * a.inv_count;
+    const float v = sum_strided<64>(a.hpart + 10 * Hp + 15 + threadIdx.x, a.h_stride, a.h_n) * a.inv_count;
     a.stats[threadIdx.x == 2 ? 3 : threadIdx.x] += v;  // single writer
   }
   if (a.step_counter && blockIdx.x == 0 && threadIdx.x == 4) *a.step_counter += 1;  // read by the adam kernel that follows
@@ -1048,7 +1058,17 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   a.clip_range = clip_range; a.ent_coef = ent_coef; a.vf_coef = vf_coef; a.inv_count = inv_count;
   a.dz2 = m->dz2;
   a.hpart = m->hpart; a.hpart_stride = 10 * Hp + 32;
-  hipLaunchKernelGGL(head_train_kernel, dim3((n + HEAD_ROWS - 1) / HEAD_ROWS), dim3(256), sizeof(float) * (HEADS * Hp + HEAD_ROWS * 8 + 24 + 2 * HEAD_ROWS * (Hp + 4)), stream, a);
+  {
+    const dim3 hgrid((n + HEAD_ROWS - 1) / HEAD_ROWS);
+    const size_t hbytes = sizeof(float) * (HEADS * Hp + HEAD_ROWS * 8 + 24 + 2 * HEAD_ROWS * (Hp + 4));
+    if (Hp == 256) {
+      HIP_TRY(hipFuncSetAttribute((const void*)head_train_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hbytes));
+      hipLaunchKernelGGL(head_train_kernel<256>, hgrid, dim3(256), hbytes, stream, a);
+    } else {
+      HIP_TRY(hipFuncSetAttribute((const void*)head_train_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hbytes));
+      hipLaunchKernelGGL(head_train_kernel<128>, hgrid, dim3(256), hbytes, stream, a);
+    }
+  }
 
   // dZ1 = (dZ2 W2) * (1 - h1^2), bias-1 gradient = column sums of dZ1 (into a padded scratch, copied below by the TN stage)
   GemmNT g{};

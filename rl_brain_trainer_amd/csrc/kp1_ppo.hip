@@ -41,27 +41,60 @@ __global__ void __launch_bounds__(256) bootstrap_kernel(float* __restrict__ rewa
   if ((d & KP1_DONE_TRUNCATED) && !(d & KP1_DONE_TERMINATED)) rewards[k] += gamma * tv[k];
 }
 
-// PointCurriculumCallback._on_step; callbacks.py:71-92.  One wave: 64-env chunks are skipped with a ballot when no
-// episode ended (the common case: 95 of 96 steps); finished episodes are replayed in env order by lane 0.
+// PointCurriculumCallback._on_step; callbacks.py:71-92.  One wave.  Each lane loads 64 consecutive done bytes (4 x 16 B)
+// and condenses them into a 64-bit done mask and a success mask, so 4096 envs cost one round of loads; a ballot skips
+// the common case where no episode ended (95 of 96 steps at Stage 5).  Finished episodes are then replayed strictly in
+// env order by lane 0 (the masks of lane k are fetched with a shuffle), which is what the reference's sequential scan does.
 __global__ void __launch_bounds__(64) curriculum_kernel(kp1_curriculum_state* __restrict__ st, const uint8_t* __restrict__ dones, int n,
                                                         int steps_per_call) {
   const int lane = threadIdx.x;
   if (lane == 0) st->num_timesteps += steps_per_call;
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    const uint8_t d = i < n ? dones[i] : 0;
-    const bool done = (d & (KP1_DONE_TERMINATED | KP1_DONE_TRUNCATED)) != 0;
-    const unsigned long long done_mask = __ballot(done);
-    if (done_mask == 0ull) continue;
-    const unsigned long long succ_mask = __ballot(done && (d & KP1_DONE_SUCCESS));
+  for (int base = 0; base < n; base += 64 * 64) {
+    const int first = base + lane * 64;
+    unsigned long long dmask = 0ull, smask = 0ull;
+    if (first + 64 <= n && (reinterpret_cast<uintptr_t>(dones + first) & 15) == 0) {
+      const uint4* p = reinterpret_cast<const uint4*>(dones + first);
+      uint4 w[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = p[q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned int words[4] = {w[q].x, w[q].y, w[q].z, w[q].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const unsigned int d = (words[k] >> (8 * b)) & 0xffu;
+            const int bit = q * 16 + k * 4 + b;
+            if (d & (KP1_DONE_TERMINATED | KP1_DONE_TRUNCATED)) {
+              dmask |= 1ull << bit;
+              if (d & KP1_DONE_SUCCESS) smask |= 1ull << bit;
+            }
+          }
+      }
+    } else {
+      for (int b = 0; b < 64 && first + b < n; ++b) {
+        const uint8_t d = dones[first + b];
+        if (d & (KP1_DONE_TERMINATED | KP1_DONE_TRUNCATED)) {
+          dmask |= 1ull << b;
+          if (d & KP1_DONE_SUCCESS) smask |= 1ull << b;
+        }
+      }
+    }
+    if (__ballot(dmask != 0ull) == 0ull) continue;
+    int stage = 0, count = 0, len = 0, head = 0, window = 1;
     if (lane == 0) {
-      unsigned long long m = done_mask;
-      int stage = st->stage_index, count = st->stage_episode_count, len = st->ring_len, head = st->ring_head;
-      const int window = st->window_episodes;
+      stage = st->stage_index; count = st->stage_episode_count; len = st->ring_len; head = st->ring_head;
+      window = st->window_episodes;
+    }
+    for (int src = 0; src < 64; ++src) {
+      unsigned long long m = __shfl(dmask, src);
+      const unsigned long long sm = __shfl(smask, src);
+      if (lane != 0) continue;
       while (m) {
         const int b = __ffsll((long long)m) - 1;
         m &= m - 1;
-        const int success = (int)((succ_mask >> b) & 1ull);
+        const int success = (int)((sm >> b) & 1ull);
         count += 1;
         if (len < window) {
           st->ring[(head + len) % window] = success;
@@ -91,6 +124,8 @@ __global__ void __launch_bounds__(64) curriculum_kernel(kp1_curriculum_state* __
           head = 0;
         }
       }
+    }
+    if (lane == 0) {
       st->stage_index = stage;
       st->stage_episode_count = count;
       st->ring_len = len;
