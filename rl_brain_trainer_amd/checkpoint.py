@@ -1,0 +1,132 @@
+"""Policy checkpoints in the Stable-Baselines3 ``.zip`` layout.
+
+The Gazebo/RViz demo and every evaluator of the reference load policies with ``PPO.load(path)``
+(kinematic_phase1/eval/eval_deterministic.py:66-79, v5/phase3a_controlled_sim.py:94-103) and call
+``model.predict(obs_dict, deterministic=True)``.  An SB3 archive (pin: stable-baselines3==2.8.0,
+final_codes_docker/Dockerfile.demo:32) contains
+
+    data                         JSON; non-JSON values are {":type:", ":serialized:" = base64(cloudpickle)}
+    policy.pth                   torch state_dict (log_std, mlp_extractor.{policy,value}_net.{0,2}.{weight,bias},
+                                 action_net.*, value_net.*); first-layer columns in alphabetical Dict-key order
+    policy.optimizer.pth         torch Adam state_dict
+    pytorch_variables.pth        {} for PPO
+    _stable_baselines3_version   text
+    system_info.txt              text
+
+``save`` writes all six members.  The tensors are exact and loadable by anything that reads SB3 state dicts.
+The cloudpickled ``observation_space`` / ``action_space`` / schedules inside ``data`` can only be produced where
+gymnasium + SB3 are importable, which is not the case in this image (and SB3 is absent from the reference tree):
+those entries are written as plain descriptions and ``tools/finish_sb3_zip.py`` re-saves the archive through SB3's
+own ``PPO.save`` on a box that has it.  Until that has been done on real SB3, ``PPO.load`` compatibility is
+UNVERIFIED -- this module never claims otherwise.
+
+``load_policy_state_dict`` reads ``policy.pth`` from any SB3 zip (reference-trained 2x64 checkpoints included) with
+``torch.load(weights_only=True)``: nothing from the archive is executed.
+"""
+from __future__ import annotations
+
+import io
+import json
+import platform
+import zipfile
+from pathlib import Path
+from typing import Any
+
+import torch
+
+from . import config as kcfg
+
+SB3_VERSION_PIN = "2.8.0"
+
+
+def _policy_data(ppo, env_cfg: kcfg.EnvConfig | None) -> dict[str, Any]:
+    cfg = ppo.cfg
+    H = cfg.hidden
+    obs_space = {k: {"shape": [n], "low": (0.0 if k in ("task_type", "mode_flag", "progress", "joint_limit_margin") else -1.0), "high": 1.0,
+                     "dtype": "float32"} for k, (_, n) in kcfg.OBS_LAYOUT.items()}
+    return {
+        "policy_class": {":type:": "<class 'abc.ABCMeta'>", "__module__": "stable_baselines3.common.policies",
+                         "__name__": "MultiInputActorCriticPolicy", ":serialized:": None},
+        "policy_kwargs": {} if H == 64 else {"net_arch": {"pi": [H, H], "vf": [H, H]}},
+        "observation_space": {":type:": "<class 'gymnasium.spaces.dict.Dict'>", ":serialized:": None, "spaces": obs_space},
+        "action_space": {":type:": "<class 'gymnasium.spaces.box.Box'>", ":serialized:": None, "shape": [kcfg.NJ], "low": -1.0, "high": 1.0,
+                         "dtype": "float32"},
+        "n_envs": int(ppo.n_envs * ppo.dist.world_size),
+        "num_timesteps": int(ppo.num_timesteps),
+        "_total_timesteps": int(cfg.total_timesteps),
+        "seed": int(cfg.seed),
+        "learning_rate": float(cfg.learning_rate),
+        "lr_schedule": {":type:": "<class 'stable_baselines3.common.utils.FloatSchedule'>", ":serialized:": None, "value": float(cfg.learning_rate)},
+        "clip_range": {":type:": "<class 'stable_baselines3.common.utils.FloatSchedule'>", ":serialized:": None, "value": float(cfg.clip_range)},
+        "n_steps": int(cfg.n_steps), "batch_size": int(cfg.batch_size), "n_epochs": int(cfg.n_epochs),
+        "gamma": float(cfg.gamma), "gae_lambda": float(cfg.gae_lambda), "ent_coef": float(cfg.ent_coef), "vf_coef": float(cfg.vf_coef),
+        "max_grad_norm": float(cfg.max_grad_norm), "normalize_advantage": bool(cfg.normalize_advantage),
+        "use_sde": False, "sde_sample_freq": -1, "target_kl": None, "clip_range_vf": None,
+        "_n_updates": int(ppo.adam_t),
+        "kp1_engine": {"writer": "rl_brain_trainer_amd.checkpoint", "needs": "tools/finish_sb3_zip.py on a host with stable-baselines3==" + SB3_VERSION_PIN,
+                       "mode": env_cfg.mode_name if env_cfg else None},
+    }
+
+
+def _torch_bytes(obj: Any) -> bytes:
+    buf = io.BytesIO()
+    torch.save(obj, buf)
+    return buf.getvalue()
+
+
+def optimizer_state_dict(ppo) -> dict[str, Any]:
+    """torch.optim.Adam.state_dict() of the flat Adam moments, one entry per SB3 parameter (policy.parameters() order)."""
+    state, off = {}, 0
+    step = torch.tensor(float(ppo.adam_t))
+    for i, (name, shape) in enumerate(ppo.policy.spec):
+        n = 1
+        for d in shape:
+            n *= d
+        state[i] = {"step": step.clone(), "exp_avg": ppo.adam_m[off:off + n].view(shape).detach().cpu().clone(),
+                    "exp_avg_sq": ppo.adam_v[off:off + n].view(shape).detach().cpu().clone()}
+        off += n
+    group = {"lr": float(ppo.cfg.learning_rate), "betas": (0.9, 0.999), "eps": float(ppo.cfg.adam_eps), "weight_decay": 0, "amsgrad": False,
+             "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+             "params": list(range(len(ppo.policy.spec)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def save(path: str | Path, ppo, env_cfg: kcfg.EnvConfig | None = None) -> Path:
+    """model.save(path): writes ``<path>.zip`` (SB3 appends the suffix the same way)."""
+    path = Path(path)
+    if path.suffix != ".zip":
+        path = path.with_name(path.name + ".zip")
+    path.parent.mkdir(parents=True, exist_ok=True)
+    with zipfile.ZipFile(path, "w", compression=zipfile.ZIP_DEFLATED) as z:
+        z.writestr("data", json.dumps(_policy_data(ppo, env_cfg), indent=4))
+        z.writestr("pytorch_variables.pth", _torch_bytes({}))
+        z.writestr("policy.pth", _torch_bytes(ppo.policy.state_dict()))
+        z.writestr("policy.optimizer.pth", _torch_bytes(optimizer_state_dict(ppo)))
+        z.writestr("_stable_baselines3_version", SB3_VERSION_PIN)
+        z.writestr("system_info.txt", f"- OS: {platform.platform()}\n- Python: {platform.python_version()}\n- PyTorch: {torch.__version__}\n"
+                                      f"- Writer: rl_brain_trainer_amd (MI355X engine); finish with tools/finish_sb3_zip.py for SB3 {SB3_VERSION_PIN}\n")
+    return path
+
+
+def load_policy_state_dict(path: str | Path) -> dict[str, torch.Tensor]:
+    """policy.pth of an SB3 zip (or a bare .pth) as a plain tensor dict; safe loader only."""
+    path = Path(path)
+    if path.suffix != ".zip" and not path.exists():
+        path = path.with_name(path.name + ".zip")
+    if path.suffix == ".zip":
+        with zipfile.ZipFile(path) as z:
+            raw = z.read("policy.pth")
+        return torch.load(io.BytesIO(raw), map_location="cpu", weights_only=True)
+    return torch.load(path, map_location="cpu", weights_only=True)
+
+
+def load_data(path: str | Path) -> dict[str, Any]:
+    path = Path(path)
+    if path.suffix != ".zip":
+        path = path.with_name(path.name + ".zip")
+    with zipfile.ZipFile(path) as z:
+        return json.loads(z.read("data"))
+
+
+def hidden_from_state_dict(sd: dict[str, torch.Tensor]) -> int:
+    return int(sd["mlp_extractor.policy_net.0.weight"].shape[0])

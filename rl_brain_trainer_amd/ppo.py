@@ -160,9 +160,9 @@ class Dist:
     def all_gather_bytes(self, t: torch.Tensor) -> torch.Tensor:
         if not self.enabled:
             return t
-        out = torch.empty((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        self.dist.all_gather_into_tensor(out, t)
-        return out.view(-1)
+        out = torch.empty(self.world_size * t.numel(), dtype=t.dtype, device=t.device)  # rank-major = global env order
+        self.dist.all_gather_into_tensor(out, t.contiguous().view(-1))
+        return out
 
     def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         if self.enabled:
@@ -390,12 +390,8 @@ class PPO:
         world = self.dist.world_size
         adv_stats = None
         if cfg.normalize_advantage and self.dist.enabled:
-            a = adv[idx]
-            s = torch.stack([a.sum(), (a * a).sum(), torch.tensor(float(n), device=a.device)])
-            self.dist.all_reduce_sum(s)
-            mean = s[0] / s[2]
-            var = ((s[1] - s[2] * mean * mean) / (s[2] - 1.0)).clamp_min(0)
-            adv_stats = torch.stack([mean, 1.0 / (var.sqrt() + 1e-8)]).float()
+            mean, inv_std = global_advantage_stats(adv[idx], self.dist)
+            adv_stats = torch.stack([mean, inv_std]).float()
         self._mlp.loss_grad(obs, idx, n, act, old_logp, adv, ret, clip_range=cfg.clip_range, ent_coef=cfg.ent_coef / world, vf_coef=cfg.vf_coef,
                             inv_count=1.0 / (n * world), grad_out=self.grad, stats_out=self.stats_dev, adv_stats=adv_stats,
                             normalize=cfg.normalize_advantage)
@@ -481,6 +477,73 @@ class PPO:
                 print(f"[ppo] it={it} steps={self.num_timesteps} fps={(self.num_timesteps - start_steps) / dt:,.0f} stage={stage} "
                       f"rew={self.rew_buf.mean().item():.4f} {self.last_stats}", flush=True)
         return self
+
+
+class InferencePolicy:
+    """``PPO.load(path)`` + ``model.predict(obs, deterministic=True)`` for evaluators and the demo loaders
+    (eval_deterministic.py:66-79, eval_three_stage.py:25-27): mean action clipped to the action space."""
+
+    def __init__(self, state_dict: dict[str, torch.Tensor], device: torch.device | int = 0, max_batch: int = 8192) -> None:
+        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        hidden = int(state_dict["mlp_extractor.policy_net.0.weight"].shape[0])
+        self.policy = ActorCritic(hidden, self.device)
+        self.policy.load_state_dict(state_dict)
+        self._mlp = None
+        if hidden in (128, 256):
+            from . import mlp as _mlp
+
+            self._mlp = _mlp.MlpKernels(hidden, self.device, max_batch=max_batch)
+            self._mlp.pack(self.policy.flat)
+
+    @classmethod
+    def load(cls, path: str, device: torch.device | int = 0, max_batch: int = 8192) -> "InferencePolicy":
+        from . import checkpoint
+
+        return cls(checkpoint.load_policy_state_dict(path), device=device, max_batch=max_batch)
+
+    @torch.no_grad()
+    def predict(self, obs: torch.Tensor, deterministic: bool = True) -> torch.Tensor:
+        if not deterministic:
+            raise NotImplementedError("evaluators use deterministic=True")
+        if self._mlp is not None:
+            mean, _ = self._mlp.mean_value(obs.contiguous())
+        else:
+            mean, _ = mlp_forward(self.policy.views, obs[:, :OBS_DIM].contiguous())
+        return mean.clamp(-1.0, 1.0)
+
+    __call__ = predict
+
+
+def ppo_loss_and_grad_torch(flat: torch.Tensor, spec, obs, act, old_logp, adv, ret, *, clip_range: float, ent_coef: float, vf_coef: float,
+                            world_size: int = 1) -> torch.Tensor:
+    """SB3's PPO loss on plain torch (any device), gradient w.r.t. the flat parameter vector, scaled so that summing the
+    result over ``world_size`` equal shards gives the single-process gradient.  Used by the CPU/gloo data-parallel tests."""
+    flat = flat.detach().clone().requires_grad_(True)
+    P, off = {}, 0
+    for name, shape in spec:
+        n = math.prod(shape)
+        P[name] = flat[off:off + n].view(shape)
+        off += n
+    mean, value = mlp_forward(P, obs)
+    logp = gaussian_log_prob(act, mean, P["log_std"])
+    ratio = torch.exp(logp - old_logp)
+    denom = float(obs.shape[0] * world_size)
+    pl = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - clip_range, 1 + clip_range)).sum() / denom
+    vl = ((ret - value) ** 2).sum() / denom
+    ent = (0.5 + LOG_SQRT_2PI + P["log_std"]).sum()
+    loss = pl + vf_coef * vl - ent_coef * ent / world_size
+    (grad,) = torch.autograd.grad(loss, flat)
+    return grad
+
+
+def global_advantage_stats(adv: torch.Tensor, dist: "Dist") -> tuple[torch.Tensor, torch.Tensor]:
+    """(mean, 1/(std + 1e-8)) of the advantages of ALL ranks (unbiased std), via one all-reduce of (sum, sum^2, count):
+    makes the normalisation, and hence the update, independent of how the minibatch is sharded over GPUs."""
+    s = torch.stack([adv.sum(), (adv * adv).sum(), torch.tensor(float(adv.numel()), device=adv.device, dtype=adv.dtype)])
+    dist.all_reduce_sum(s)
+    mean = s[0] / s[2]
+    var = ((s[1] - s[2] * mean * mean) / (s[2] - 1.0)).clamp_min(0)
+    return mean, 1.0 / (var.sqrt() + 1e-8)
 
 
 def smoke() -> dict[str, Any]:
