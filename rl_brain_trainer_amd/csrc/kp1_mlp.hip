@@ -29,7 +29,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: arra
 namespace {
 
 constexpr int IN = KP1_MLP_IN, INP = KP1_MLP_IN_PAD, ACT = KP1_MLP_ACT, HEADS = 8;
-constexpr int BK = 32, LDT = BK + 4;  // LDS row pitch 36 floats: ds_read_b128 conflict-free (guide: pad by one access width)
 constexpr float LOG_SQRT_2PI = 0.9189385332046727f;
 
 enum { EPI_BIAS_TANH = 0, EPI_DTANH = 1 };
@@ -64,18 +63,18 @@ struct GemmNT {
 // never re-read.  4 waves, each 64 columns wide (2 MFMA column blocks) and RB row blocks tall.
 // amdgpu_waves_per_eu(1, 2): the 140 KB LDS footprint allows one workgroup (one wave per SIMD) per CU anyway; without
 // the hint hipcc spills the prefetch registers to scratch to stay under the 256-register budget of two waves per SIMD.
-template <int BN, int EPI, int K>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) gemm_nt_kernel(const GemmNT g) {
-  constexpr int BM = 64;
-  constexpr int KQ = K / 4, A_LOADS = BM * KQ / 256;  // float4 per A row / per thread: all issued before any is used
-  constexpr int WN = BN / 64, WM = 4 / WN;
+template <int BN, int EPI, int K, int NTH, int BM, int BKS>
+__global__ void __launch_bounds__(NTH) gemm_nt_kernel(const GemmNT g) {
+  constexpr int NW = NTH / 64, LDS_T = BKS + 4, KC = BKS / 4;  // BKS = k depth of one W stage, LDS_T its LDS pitch  // NTH = 512: two waves per SIMD share the MFMA pipe and split the epilogue VALU work
+  constexpr int KQ = K / 4, A_LOADS = BM * KQ / NTH;  // float4 per A row / per thread: all issued before any is used
+  constexpr int WN = BN / 64, WM = NW / WN;
   constexpr int RB = BM / WM / 32, CB = 2;
-  constexpr int W_LOADS = BN * 8 / 256;
+  constexpr int W_LOADS = BN * KC / NTH;
   extern __shared__ float lds[];
   constexpr int lda_s = K + 4;               // LDS pitch of the resident A block (bank-conflict-free b128 reads)
   float* As = lds;
   float* Ws0 = lds + BM * lda_s;
-  float* Ws1 = Ws0 + BN * LDT;
+  float* Ws1 = Ws0 + BN * LDS_T;
 
   const int z = blockIdx.z;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -87,20 +86,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   // ---- prologue: W stages 0 and 1 to registers, whole A block to LDS.  W is prefetched TWO stages ahead (register
   // sets rwa / rwb alternate): with one wave per SIMD nothing else hides an L2 round trip, and one 4096-cycle stage
   // of cover was not enough under 256 workgroups streaming the same W.
-  constexpr int KT = K / BK;
+  constexpr int KT = K / BKS;
   f32x4 rwa[W_LOADS], rwb[W_LOADS];
 #define KP1_NT_WLOAD(dst, stage)                                                                        \
   {                                                                                                     \
-    const int kk = ((stage) < KT ? (stage) : KT - 1) * BK;                                              \
+    const int kk = ((stage) < KT ? (stage) : KT - 1) * BKS;                                              \
     _Pragma("unroll") for (int j = 0; j < W_LOADS; ++j) {                                               \
-      const int f = tid + 256 * j;                                                                      \
-      dst[j] = *reinterpret_cast<const f32x4*>(W + (int64_t)(f >> 3) * K + kk + 4 * (f & 7));           \
+      const int f = tid + NTH * j;                                                                      \
+      dst[j] = *reinterpret_cast<const f32x4*>(W + (int64_t)(f / KC) * K + kk + 4 * (f % KC));           \
     }                                                                                                   \
   }
 #define KP1_NT_WSTORE(src, ws)                                                                          \
   _Pragma("unroll") for (int j = 0; j < W_LOADS; ++j) {                                                 \
-    const int f = tid + 256 * j;                                                                        \
-    *reinterpret_cast<f32x4*>((ws) + (f >> 3) * LDT + 4 * (f & 7)) = src[j];                            \
+    const int f = tid + NTH * j;                                                                        \
+    *reinterpret_cast<f32x4*>((ws) + (f / KC) * LDS_T + 4 * (f % KC)) = src[j];                            \
   }
   KP1_NT_WLOAD(rwa, 0)
   KP1_NT_WLOAD(rwb, 1)
@@ -110,17 +109,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     f32x4 av[A_LOADS];
 #pragma unroll
     for (int j = 0; j < A_LOADS; ++j) {
-      const int m = min(m0 + (tid + 256 * j) / KQ, g.M - 1);
+      const int m = min(m0 + (tid + NTH * j) / KQ, g.M - 1);
       arow[j] = g.gather ? g.gather[m] : (int64_t)m;
     }
 #pragma unroll
     for (int j = 0; j < A_LOADS; ++j) {
-      const int k = 4 * ((tid + 256 * j) % KQ);
+      const int k = 4 * ((tid + NTH * j) % KQ);
       av[j] = *reinterpret_cast<const f32x4*>(A + arow[j] * g.lda + (k < g.Kreal ? k : 0));
     }
 #pragma unroll
     for (int j = 0; j < A_LOADS; ++j) {
-      const int f = tid + 256 * j, row = f / KQ, k = 4 * (f % KQ);
+      const int f = tid + NTH * j, row = f / KQ, k = 4 * (f % KQ);
       const float keep = (m0 + row < g.M && k < g.Kreal) ? 1.f : 0.f;
       *reinterpret_cast<f32x4*>(As + row * lda_s + k) = av[j] * keep;
     }
@@ -139,12 +138,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   const float* as_base = As + (wr * (BM / WM) + (lane & 31)) * lda_s + 4 * (lane >> 5);
 #define KP1_NT_COMPUTE(kt_, ws_cur_)                                                                    \
   {                                                                                                     \
-    const float* as = as_base + (kt_) * BK;                                                             \
-    const float* ws = (ws_cur_) + (wc * 64 + (lane & 31)) * LDT + 4 * (lane >> 5);                      \
-    _Pragma("unroll") for (int kg = 0; kg < BK / 8; ++kg) {                                             \
+    const float* as = as_base + (kt_) * BKS;                                                             \
+    const float* ws = (ws_cur_) + (wc * 64 + (lane & 31)) * LDS_T + 4 * (lane >> 5);                      \
+    _Pragma("unroll") for (int kg = 0; kg < BKS / 8; ++kg) {                                             \
       float4 a[RB], b[CB];                                                                              \
       _Pragma("unroll") for (int r = 0; r < RB; ++r) a[r] = *reinterpret_cast<const float4*>(as + r * 32 * lda_s + kg * 8); \
-      _Pragma("unroll") for (int c = 0; c < CB; ++c) b[c] = *reinterpret_cast<const float4*>(ws + c * 32 * LDT + kg * 8);   \
+      _Pragma("unroll") for (int c = 0; c < CB; ++c) b[c] = *reinterpret_cast<const float4*>(ws + c * 32 * LDS_T + kg * 8);   \
       _Pragma("unroll") for (int r = 0; r < RB; ++r)                                                    \
         _Pragma("unroll") for (int c = 0; c < CB; ++c) {                                                \
           acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].x, b[c].x, acc[r][c], 0, 0, 0);         \
@@ -173,7 +172,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   // ---- epilogue: accumulators -> LDS (row-major [64][BN+4], reusing the A/W staging space) -> each thread owns
   // float4 column groups of 16 B, so bias/aux loads and the C stores are fully coalesced dwordx4 (the MFMA register
   // layout would give 64 scalar stores per lane, which are issue-bound with one wave per SIMD).
-  constexpr int LDC = BN + 4, CQ = BN / 4, C_ITERS = BM * CQ / 256;
+  constexpr int LDC = BN + 4, CQ = BN / 4, C_ITERS = BM * CQ / NTH;
   float* Cs = lds;
 #pragma unroll
   for (int c = 0; c < CB; ++c)
@@ -194,14 +193,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   if constexpr (EPI == EPI_DTANH) {
 #pragma unroll
     for (int j = 0; j < C_ITERS; ++j) {
-      const int m = min(m0 + (tid + 256 * j) / CQ, g.M - 1);
+      const int m = min(m0 + (tid + NTH * j) / CQ, g.M - 1);
       hv[j] = *reinterpret_cast<const f32x4*>(g.aux + z * g.strideAux + (int64_t)m * g.ldc + ncol);
     }
   }
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < C_ITERS; ++j) {
-    const int row = (tid + 256 * j) / CQ;
+    const int row = (tid + NTH * j) / CQ;
     const int m = m0 + row;
     f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC + 4 * c4);
     if constexpr (EPI == EPI_BIAS_TANH) {
@@ -223,7 +222,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
       if (tid < BN) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 256 / CQ; ++k) t += red[k * BN + tid];
+        for (int k = 0; k < NTH / CQ; ++k) t += red[k * BN + tid];
         g.colsum[(int64_t)blockIdx.x * 2 * g.strideColsum + z * g.strideColsum + n0 + tid] = t;
       }
     }
@@ -868,12 +867,28 @@ int mlp_check_device(const kp1_mlp* m) {
 
 constexpr size_t TN_LDS_BYTES = sizeof(float) * 2 * 2 * 64 * (128 + 4);
 
+// Tile shapes.  Wide (whole hidden width per workgroup, large batches): 64 rows x 256 columns, 32-deep W stages, 512
+// threads (two waves per SIMD split the epilogue), one workgroup per CU.  Narrow (small batches, more workgroups):
+// 64 rows x 128 columns, 256 threads.  Measured alternatives at M = 8192 (all within 7 %): 32 x 256 tiles with 16-deep
+// stages and two workgroups per CU 29.9 us, 64 x 256 / 256 threads 28.9 us, this one 28.0 us -- the three GEMM kinds all
+// plateau near 75 TFLOP/s, see DESIGN.md section 5.
 template <int BN, int EPI, int K>
 int launch_nt_inst(const GemmNT& g, hipStream_t stream) {
-  const size_t bytes = sizeof(float) * (64 * (size_t)(K + 4) + 2 * (size_t)BN * LDT);
-  HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel<BN, EPI, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  hipLaunchKernelGGL((gemm_nt_kernel<BN, EPI, K>), dim3((g.M + 63) / 64, g.N / BN, 2), dim3(256), bytes, stream, g);
+  constexpr int NTH = BN == 256 ? 512 : 256;
+  constexpr int BM = 64;
+  constexpr int BKS = 32;
+  size_t bytes = sizeof(float) * (BM * (size_t)(K + 4) + 2 * (size_t)BN * (BKS + 4));
+  const size_t epi = sizeof(float) * (BM * (size_t)(BN + 4) + (size_t)(NTH / (BN / 4)) * BN);  // C tile + bias-partial scratch
+  if (epi > bytes) bytes = epi;
+  HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel<BN, EPI, K, NTH, BM, BKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  hipLaunchKernelGGL((gemm_nt_kernel<BN, EPI, K, NTH, BM, BKS>), dim3((g.M + BM - 1) / BM, g.N / BN, 2), dim3(NTH), bytes, stream, g);
   return KP1_OK;
+}
+
+// number of row tiles launch_nt uses for an n-row GEMM with N = Hp columns (the bias-partial count of the backward GEMM)
+int nt_row_tiles(int n, int Hp) {
+  (void)Hp;
+  return (n + 63) / 64;
 }
 
 template <int EPI>
@@ -981,7 +996,7 @@ int kp1_mlp_create(int32_t device, int32_t hidden, int32_t max_batch, kp1_mlp** 
   MLP_ALLOC(m->slab, (int64_t)64 * 2 * Hp * Hp);
   MLP_ALLOC(m->slab1, (int64_t)64 * 2 * Hp * INP);
   MLP_ALLOC(m->step_dev, 4);
-  MLP_ALLOC(m->bslab, (mb / 64) * 2 * Hp);
+  MLP_ALLOC(m->bslab, (mb / 32) * 2 * Hp);
   MLP_ALLOC(m->hpart, (mb / 32) * (10 * Hp + 32));
 #undef MLP_ALLOC
   if (rc != KP1_OK) {
@@ -1104,7 +1119,7 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   f.L = L;
   f.slab2 = m->slab; f.s2_ld = Hp; f.s2_net = (int64_t)Hp * Hp; f.s2_chunk = 2 * f.s2_net; f.s2_n = s2_n;
   f.slab1 = m->slab1; f.s1_ld = INP; f.s1_net = (int64_t)Hp * INP; f.s1_chunk = 2 * f.s1_net; f.s1_n = s1_n;
-  f.bslab = m->bslab; f.b_net = Hp; f.b_tile = 2 * Hp; f.b_n = (n + 63) / 64;
+  f.bslab = m->bslab; f.b_net = Hp; f.b_tile = 2 * Hp; f.b_n = nt_row_tiles(n, Hp);
   f.hpart = m->hpart; f.h_stride = 10 * Hp + 32; f.h_n = (n + HEAD_ROWS - 1) / HEAD_ROWS;
   f.ent_coef = ent_coef; f.inv_count = inv_count; f.log_std = m->k.log_std;
   f.grad = grad_out; f.stats = stats_out; f.sumsq = m->partials + 2 * N_PARTIALS;
