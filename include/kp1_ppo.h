@@ -104,6 +104,13 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
                       const float* adv_stats_dev, float clip_range, float ent_coef, float vf_coef, float inv_count, float* grad_out,
                       float* stats_out, int32_t grad_is_zero, void* stream);
 
+/* Options.  KP1_MLP_OPT_FUSED (default 1): for hidden = 256, kp1_mlp_loss_grad runs layer 1, layer 2, the heads, the PPO loss
+ * and the activation backward of a 32-row minibatch tile in one workgroup (mlp_train_tile_kernel) instead of four
+ * chip-synchronous launches; 0 selects the layer-wise kernels (always used for hidden = 128).  Same results up to fp32
+ * summation order of the per-tile partials. */
+#define KP1_MLP_OPT_FUSED 1
+int kp1_mlp_set_option(kp1_mlp* m, int32_t option, int32_t value);
+
 /* clip_grad_norm_(max_norm) + Adam(beta 0.9/0.999, eps) step on the flat vectors; the same pass repacks the kernel-format
  * weights.  step = 1-based Adam step count, or <= 0 to use the device-resident counter that every kp1_mlp_loss_grad call
  * increments (needed when the call sequence is replayed from a hipGraph).  flags bit 1 (value 2): grad is untouched since the kp1_mlp_loss_grad call that

@@ -33,6 +33,20 @@ constexpr float LOG_SQRT_2PI = 0.9189385332046727f;
 
 enum { EPI_BIAS_TANH = 0, EPI_DTANH = 1 };
 
+// Developer timeline (tools/nt_timeline.py builds a private copy of the library with -DKP1_NT_TRACE): thread 0 of every
+// workgroup stamps the 100 MHz wall clock at the phase boundaries of gemm_nt_kernel.  Compiled out of the product.
+#ifdef KP1_NT_TRACE
+constexpr int KP1_TRACE_SLOTS = 16, KP1_TRACE_WGS = 1024;
+__device__ unsigned long long kp1_nt_trace_buf[KP1_TRACE_SLOTS * KP1_TRACE_WGS];
+#define KP1_TR(slot)                                                                                          \
+  if (threadIdx.x == 0) {                                                                                     \
+    const int wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                           \
+    if (wg_ < KP1_TRACE_WGS) kp1_nt_trace_buf[wg_ * KP1_TRACE_SLOTS + (slot)] = wall_clock64();               \
+  }
+#else
+#define KP1_TR(slot)
+#endif
+
 // Branch-free tanh (the epilogue runs one wave per SIMD, so every VALU slot is exposed; ocml's tanhf costs ~45
 // instructions plus divergent branches).  |x| < 0.25: odd Taylor polynomial through x^9 (truncation < 1e-8 relative);
 // else 1 - 2 / (2^(2 log2(e) |x|) + 1) on v_exp_f32 / v_rcp_f32.  Absolute error <= ~2e-7 (fp32 rounding of values near 1),
@@ -48,7 +62,7 @@ __device__ __forceinline__ float kp_tanh(float x) {
 struct GemmNT {
   const float* A; int64_t lda; int64_t strideA;       // [M][lda], per-net stride
   const int64_t* gather;                               // optional row indices into A (shared by both nets)
-  const float* W; int64_t strideW;                     // [N][K] row-major
+  const float* W; int64_t strideW;                     // k-slab major [K/32][N][32] (struct Packed)
   const float* bias; int64_t strideBias;               // [N]
   float* C; int64_t ldc; int64_t strideC;              // [M][ldc]
   const float* aux; int64_t strideAux;                 // EPI_DTANH: activation H at C's coordinates (ld = ldc)
@@ -79,7 +93,7 @@ __global__ void __launch_bounds__(NTH) gemm_nt_kernel(const GemmNT g) {
   const int z = blockIdx.z;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const float* __restrict__ A = g.A + z * g.strideA;
-  const float* __restrict__ W = g.W + z * g.strideW + (int64_t)n0 * K;
+  const float* __restrict__ W = g.W + z * g.strideW + (int64_t)n0 * 32;  // k-slab major: [K/32][N][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN;
 
@@ -93,7 +107,7 @@ __global__ void __launch_bounds__(NTH) gemm_nt_kernel(const GemmNT g) {
     const int kk = ((stage) < KT ? (stage) : KT - 1) * BKS;                                              \
     _Pragma("unroll") for (int j = 0; j < W_LOADS; ++j) {                                               \
       const int f = tid + NTH * j;                                                                      \
-      dst[j] = *reinterpret_cast<const f32x4*>(W + (int64_t)(f / KC) * K + kk + 4 * (f % KC));           \
+      dst[j] = *reinterpret_cast<const f32x4*>(W + (int64_t)(kk >> 5) * g.N * 32 + (f / KC) * 32 + (kk & 31) + 4 * (f % KC)); \
     }                                                                                                   \
   }
 #define KP1_NT_WSTORE(src, ws)                                                                          \
@@ -101,6 +115,7 @@ __global__ void __launch_bounds__(NTH) gemm_nt_kernel(const GemmNT g) {
     const int f = tid + NTH * j;                                                                        \
     *reinterpret_cast<f32x4*>((ws) + (f / KC) * LDS_T + 4 * (f % KC)) = src[j];                            \
   }
+  KP1_TR(0)
   KP1_NT_WLOAD(rwa, 0)
   KP1_NT_WLOAD(rwb, 1)
   {
@@ -126,6 +141,7 @@ __global__ void __launch_bounds__(NTH) gemm_nt_kernel(const GemmNT g) {
   }
   KP1_NT_WSTORE(rwa, Ws0)
   __syncthreads();
+  KP1_TR(1)
 
   f32x16 acc[RB][CB];
 #pragma unroll
@@ -164,6 +180,7 @@ __global__ void __launch_bounds__(NTH) gemm_nt_kernel(const GemmNT g) {
     KP1_NT_COMPUTE(kt + 1, Ws1)
     KP1_NT_WSTORE(rwa, Ws0)            // stage kt+2
     __syncthreads();
+    KP1_TR(2 + kt / 2)
   }
 #undef KP1_NT_WLOAD
 #undef KP1_NT_WSTORE
@@ -184,6 +201,7 @@ __global__ void __launch_bounds__(NTH) gemm_nt_kernel(const GemmNT g) {
         Cs[row * LDC + wc * 64 + c * 32 + (lane & 31)] = acc[r][c][e];
       }
   __syncthreads();
+  KP1_TR(10)
   float* __restrict__ C = g.C + z * g.strideC;
   const int c4 = tid % CQ;                      // fixed column group per thread
   const int ncol = n0 + 4 * c4;
@@ -212,6 +230,7 @@ __global__ void __launch_bounds__(NTH) gemm_nt_kernel(const GemmNT g) {
     }
     if (m < g.M) *reinterpret_cast<f32x4*>(C + (int64_t)m * g.ldc + ncol) = v;
   }
+  KP1_TR(11)
   if constexpr (EPI == EPI_DTANH) {
     if (g.colsum) {
       // bias-gradient partial of this row block: threads tid, tid + CQ, ... own the same column group; combine them in
@@ -640,9 +659,15 @@ __host__ __device__ inline ParamLayout make_layout(int H) {
   return L;
 }
 
+// Kernel-format GEMM weights are "k-slab major": W[net][K/32][N][32], i.e. element (out row n, in column k) of a net sits
+// at (k/32)*N*32 + n*32 + k%32.  One 32-deep W stage of a GEMM is then ONE contiguous N*128-byte run.  With the natural
+// row-major [N][K] layout a stage is N separate 128-byte pieces at a 1 KB pitch, which (256-byte channel interleave) land
+// on 4 of the 16 L2 channels of an XCD -- every CU streams the same stage at the same time, and the MFMA loops of all
+// three GEMM kinds sat at ~50 % waiting on those four channels.
 struct Packed {
-  float *w1p, *b1, *w2, *w2t, *b2, *w3, *b3, *log_std;  // [2][Hp][64], [2][Hp], [2][Hp][Hp], [2][Hp][Hp], [2][Hp], [8][Hp], [8], [8]
+  float *w1p, *b1, *w2, *w2t, *b2, *w3, *b3, *log_std;  // [2][2][Hp][32], [2][Hp], [2][Hp/32][Hp][32] x2, [2][Hp], [8][Hp], [8], [8]
 };
+__host__ __device__ inline int64_t slab_at(int64_t n, int64_t k, int64_t N) { return (k >> 5) * N * 32 + n * 32 + (k & 31); }
 
 // flat SB3 vector element i -> its place(s) in the kernel-format weights (zero padding pre-set once at creation)
 __device__ __forceinline__ void pack_one(int64_t i, float v, const ParamLayout& L, const Packed& k) {
@@ -651,24 +676,24 @@ __device__ __forceinline__ void pack_one(int64_t i, float v, const ParamLayout& 
     k.log_std[i] = v;
   } else if (i < L.p_b1) {
     const int64_t e = i - L.p_w1;
-    k.w1p[(e / IN) * INP + e % IN] = v;
+    k.w1p[slab_at(e / IN, e % IN, Hp)] = v;
   } else if (i < L.p_w2) {
     k.b1[i - L.p_b1] = v;
   } else if (i < L.p_b2) {
     const int64_t e = i - L.p_w2, r = e / H, c = e % H;
-    k.w2[r * Hp + c] = v;
-    k.w2t[c * Hp + r] = v;
+    k.w2[slab_at(r, c, Hp)] = v;
+    k.w2t[slab_at(c, r, Hp)] = v;
   } else if (i < L.v_w1) {
     k.b2[i - L.p_b2] = v;
   } else if (i < L.v_b1) {
     const int64_t e = i - L.v_w1;
-    k.w1p[(int64_t)Hp * INP + (e / IN) * INP + e % IN] = v;
+    k.w1p[(int64_t)Hp * INP + slab_at(e / IN, e % IN, Hp)] = v;
   } else if (i < L.v_w2) {
     k.b1[Hp + i - L.v_b1] = v;
   } else if (i < L.v_b2) {
     const int64_t e = i - L.v_w2, r = e / H, c = e % H;
-    k.w2[(int64_t)Hp * Hp + r * Hp + c] = v;
-    k.w2t[(int64_t)Hp * Hp + c * Hp + r] = v;
+    k.w2[(int64_t)Hp * Hp + slab_at(r, c, Hp)] = v;
+    k.w2t[(int64_t)Hp * Hp + slab_at(c, r, Hp)] = v;
   } else if (i < L.a_w) {
     k.b2[Hp + i - L.v_b2] = v;
   } else if (i < L.a_b) {
@@ -824,6 +849,8 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float*
   if (zero_grad) g[i] = 0.f;
 }
 
+#include "kp1_mlp_fused.inc"
+
 }  // namespace
 
 // ============================================================================================ host
@@ -843,6 +870,7 @@ struct kp1_mlp {
   int n_finalize_blocks = 0;   // sum-of-squares partials written by the last grad_finalize_kernel
   int* step_dev = nullptr;     // device Adam step counter
   int last_s2_n = 0, last_s1_n = 0;
+  int fused = 1;               // KP1_MLP_OPT_FUSED: one workgroup carries a row tile through the whole chain (H = 256 only)
   std::vector<void*> allocs;
 };
 
@@ -905,6 +933,13 @@ int launch_nt(const GemmNT& g, hipStream_t stream) {
 
 // dW (both nets) = D^T X over n rows: split-B partial tiles into m->slab, then the fixed-order reduce into G
 int launch_tn(kp1_mlp* m, GemmTN t, int n_o_tiles, int slab_cols, float* slab, int* n_chunks_out, hipStream_t stream);
+
+int launch_fused(const FusedArgs& fa, hipStream_t stream) {
+  const size_t bytes = sizeof(float) * FU_LDS_FLOATS;
+  HIP_TRY(hipFuncSetAttribute((const void*)mlp_train_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  hipLaunchKernelGGL(mlp_train_tile_kernel, dim3((fa.n + FU_BM - 1) / FU_BM, 1, 2), dim3(FU_NTH), bytes, stream, fa);
+  return KP1_OK;
+}
 
 // forward layers 1 and 2 for n rows (both nets): h1, h2 filled
 int launch_forward_layers(kp1_mlp* m, const float* obs, int obs_stride, const int64_t* idx, int n, hipStream_t stream) {
@@ -1016,6 +1051,15 @@ int kp1_mlp_destroy(kp1_mlp* m) {
   return KP1_OK;
 }
 
+int kp1_mlp_set_option(kp1_mlp* m, int32_t option, int32_t value) {
+  if (!m) return fail(KP1_ERR_INVALID, "NULL argument");
+  if (option == KP1_MLP_OPT_FUSED) {
+    m->fused = value ? 1 : 0;
+    return KP1_OK;
+  }
+  return fail(KP1_ERR_INVALID, "unknown kp1_mlp option");
+}
+
 int kp1_mlp_pack_weights(kp1_mlp* m, const float* params, void* stream) {
   if (!m || !params) return fail(KP1_ERR_INVALID, "NULL argument");
   int rc = mlp_check_device(m);
@@ -1057,45 +1101,60 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   const int64_t act_stride = (int64_t)m->max_batch * Hp;
   const ParamLayout& L = m->L;
   (void)grad_is_zero;  // every gradient element is written (not accumulated) by grad_finalize_kernel
-  rc = launch_forward_layers(m, obs, obs_stride, idx, n, stream);
-  if (rc != KP1_OK) return rc;
-
-  HeadArgs a{};
-  a.h2 = m->h2; a.strideH = act_stride; a.Hp = Hp; a.n = n; a.H = H;
-  a.w3 = m->k.w3; a.b3 = m->k.b3; a.log_std = m->k.log_std;
-  a.idx = idx; a.actions = actions; a.old_logp = old_log_prob; a.adv = advantages; a.ret = returns;
-  a.adv_partials = m->partials; a.n_adv_partials = N_PARTIALS; a.adv_stats = adv_stats_dev; a.adv_mean = adv_mean; a.adv_inv_std = adv_inv_std;
-  if (adv_stats_dev) a.adv_mode = 2;
-  else if (adv_inv_std > 0.f) a.adv_mode = 3;
-  else if (adv_inv_std == 0.f) a.adv_mode = 1;
-  else a.adv_mode = 0;
-  if (a.adv_mode == 1) hipLaunchKernelGGL(adv_partials_kernel, dim3(N_PARTIALS), dim3(256), 0, stream, advantages, idx, n, m->partials);
-  a.clip_range = clip_range; a.ent_coef = ent_coef; a.vf_coef = vf_coef; a.inv_count = inv_count;
-  a.dz2 = m->dz2;
-  a.hpart = m->hpart; a.hpart_stride = 10 * Hp + 32;
-  {
-    const dim3 hgrid((n + HEAD_ROWS - 1) / HEAD_ROWS);
-    const size_t hbytes = sizeof(float) * (HEADS * Hp + HEAD_ROWS * 8 + 24 + 2 * HEAD_ROWS * (Hp + 4));
-    if (Hp == 256) {
-      HIP_TRY(hipFuncSetAttribute((const void*)head_train_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hbytes));
-      hipLaunchKernelGGL(head_train_kernel<256>, hgrid, dim3(256), hbytes, stream, a);
-    } else {
-      HIP_TRY(hipFuncSetAttribute((const void*)head_train_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hbytes));
-      hipLaunchKernelGGL(head_train_kernel<128>, hgrid, dim3(256), hbytes, stream, a);
+  const bool fused = m->fused && Hp == FU_HP;
+  int adv_mode = 0;
+  if (adv_stats_dev) adv_mode = 2;
+  else if (adv_inv_std > 0.f) adv_mode = 3;
+  else if (adv_inv_std == 0.f) adv_mode = 1;
+  if (adv_mode == 1) hipLaunchKernelGGL(adv_partials_kernel, dim3(N_PARTIALS), dim3(256), 0, stream, advantages, idx, n, m->partials);
+  const int hpart_stride = 10 * Hp + 32;
+  if (fused) {
+    FusedArgs fa{};
+    fa.obs = obs; fa.obs_stride = obs_stride; fa.Kreal = obs_stride >= INP ? INP : IN; fa.idx = idx; fa.n = n;
+    fa.k = m->k;
+    fa.actions = actions; fa.old_logp = old_log_prob; fa.adv = advantages; fa.ret = returns;
+    fa.adv_partials = m->partials; fa.n_adv_partials = N_PARTIALS; fa.adv_stats = adv_stats_dev; fa.adv_mean = adv_mean; fa.adv_inv_std = adv_inv_std;
+    fa.adv_mode = adv_mode;
+    fa.clip_range = clip_range; fa.vf_coef = vf_coef; fa.inv_count = inv_count;
+    fa.h1 = m->h1; fa.dz2 = m->dz2; fa.dz1 = m->dz1; fa.act_stride = act_stride;
+    fa.bslab = m->bslab; fa.hpart = m->hpart; fa.hpart_stride = hpart_stride;
+    rc = launch_fused(fa, stream);
+    if (rc != KP1_OK) return rc;
+  } else {
+    rc = launch_forward_layers(m, obs, obs_stride, idx, n, stream);
+    if (rc != KP1_OK) return rc;
+    HeadArgs a{};
+    a.h2 = m->h2; a.strideH = act_stride; a.Hp = Hp; a.n = n; a.H = H;
+    a.w3 = m->k.w3; a.b3 = m->k.b3; a.log_std = m->k.log_std;
+    a.idx = idx; a.actions = actions; a.old_logp = old_log_prob; a.adv = advantages; a.ret = returns;
+    a.adv_partials = m->partials; a.n_adv_partials = N_PARTIALS; a.adv_stats = adv_stats_dev; a.adv_mean = adv_mean; a.adv_inv_std = adv_inv_std;
+    a.adv_mode = adv_mode;
+    a.clip_range = clip_range; a.ent_coef = ent_coef; a.vf_coef = vf_coef; a.inv_count = inv_count;
+    a.dz2 = m->dz2;
+    a.hpart = m->hpart; a.hpart_stride = hpart_stride;
+    {
+      const dim3 hgrid((n + HEAD_ROWS - 1) / HEAD_ROWS);
+      const size_t hbytes = sizeof(float) * (HEADS * Hp + HEAD_ROWS * 8 + 24 + 2 * HEAD_ROWS * (Hp + 4));
+      if (Hp == 256) {
+        HIP_TRY(hipFuncSetAttribute((const void*)head_train_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hbytes));
+        hipLaunchKernelGGL(head_train_kernel<256>, hgrid, dim3(256), hbytes, stream, a);
+      } else {
+        HIP_TRY(hipFuncSetAttribute((const void*)head_train_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hbytes));
+        hipLaunchKernelGGL(head_train_kernel<128>, hgrid, dim3(256), hbytes, stream, a);
+      }
     }
+    // dZ1 = (dZ2 W2) * (1 - h1^2), bias-1 gradient partials = per-row-tile column sums of dZ1
+    GemmNT g{};
+    g.A = m->dz2; g.lda = Hp; g.strideA = act_stride; g.gather = nullptr;
+    g.W = m->k.w2t; g.strideW = (int64_t)Hp * Hp;
+    g.bias = nullptr; g.strideBias = 0;
+    g.C = m->dz1; g.ldc = Hp; g.strideC = act_stride;
+    g.aux = m->h1; g.strideAux = act_stride;
+    g.colsum = m->bslab; g.strideColsum = Hp;
+    g.M = n; g.N = Hp; g.K = Hp; g.Kreal = Hp;
+    rc = launch_nt<EPI_DTANH>(g, stream);
+    if (rc != KP1_OK) return rc;
   }
-
-  // dZ1 = (dZ2 W2) * (1 - h1^2), bias-1 gradient = column sums of dZ1 (into a padded scratch, copied below by the TN stage)
-  GemmNT g{};
-  g.A = m->dz2; g.lda = Hp; g.strideA = act_stride; g.gather = nullptr;
-  g.W = m->k.w2t; g.strideW = (int64_t)Hp * Hp;
-  g.bias = nullptr; g.strideBias = 0;
-  g.C = m->dz1; g.ldc = Hp; g.strideC = act_stride;
-  g.aux = m->h1; g.strideAux = act_stride;
-  g.colsum = m->bslab; g.strideColsum = Hp;  // per-row-block bias-gradient partials
-  g.M = n; g.N = Hp; g.K = Hp; g.Kreal = Hp;
-  rc = launch_nt<EPI_DTANH>(g, stream);
-  if (rc != KP1_OK) return rc;
 
   // weight gradients (split over the batch axis)
   GemmTN t{};
@@ -1119,7 +1178,7 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   f.L = L;
   f.slab2 = m->slab; f.s2_ld = Hp; f.s2_net = (int64_t)Hp * Hp; f.s2_chunk = 2 * f.s2_net; f.s2_n = s2_n;
   f.slab1 = m->slab1; f.s1_ld = INP; f.s1_net = (int64_t)Hp * INP; f.s1_chunk = 2 * f.s1_net; f.s1_n = s1_n;
-  f.bslab = m->bslab; f.b_net = Hp; f.b_tile = 2 * Hp; f.b_n = nt_row_tiles(n, Hp);
+  f.bslab = m->bslab; f.b_net = Hp; f.b_tile = 2 * Hp; f.b_n = fused ? (n + FU_BM - 1) / FU_BM : nt_row_tiles(n, Hp);
   f.hpart = m->hpart; f.h_stride = 10 * Hp + 32; f.h_n = (n + HEAD_ROWS - 1) / HEAD_ROWS;
   f.ent_coef = ent_coef; f.inv_count = inv_count; f.log_std = m->k.log_std;
   f.grad = grad_out; f.stats = stats_out; f.sumsq = m->partials + 2 * N_PARTIALS;
@@ -1191,6 +1250,18 @@ int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32
   (void)hipEventDestroy(e1);
   return KP1_OK;
 }
+
+#ifdef KP1_NT_TRACE
+int kp1_debug_nt_trace(unsigned long long* out, int clear) {
+  HIP_TRY(hipDeviceSynchronize());
+  if (out) HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(kp1_nt_trace_buf), sizeof(unsigned long long) * KP1_TRACE_SLOTS * KP1_TRACE_WGS));
+  if (clear) {
+    std::vector<unsigned long long> z(KP1_TRACE_SLOTS * KP1_TRACE_WGS, 0ull);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(kp1_nt_trace_buf), z.data(), sizeof(unsigned long long) * z.size()));
+  }
+  return KP1_OK;
+}
+#endif
 
 int kp1_mlp_adam_step(kp1_mlp* m, float* params, float* grad, float* exp_avg, float* exp_avg_sq, float lr, float eps, float max_grad_norm,
                       int32_t step, int32_t zero_grad, void* stream_) {

@@ -28,6 +28,7 @@ class MlpKernels:
         L.kp1_mlp_loss_grad.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, f32, f32, vp, f32, f32, f32, f32, vp, vp, i32, vp]
         L.kp1_mlp_adam_step.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, i32, i32, vp]
         L.kp1_mlp_time_kernels.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+        L.kp1_mlp_set_option.argtypes = [vp, i32, i32]
         self.hidden = hidden
         self.device = device
         self.max_batch = int(max_batch)
@@ -39,6 +40,12 @@ class MlpKernels:
         if self._h.value:
             self.L.kp1_mlp_destroy(self._h)
             self._h = C.c_void_p()
+
+    OPT_FUSED = 1
+
+    def set_fused(self, on: bool) -> None:
+        """hidden = 256: whole activation chain of a 32-row tile in one workgroup (default) vs the layer-wise kernels."""
+        native.check(self.L.kp1_mlp_set_option(self._h, self.OPT_FUSED, int(bool(on))))
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -32,6 +32,43 @@ def _policy(hidden=256, seed=3, scale_heads=True):
     return pol
 
 
+def test_fused_tile_kernel_matches_layerwise_kernels_and_is_reproducible():
+    """Same minibatch through mlp_train_tile_kernel and through gemm_nt x3 + head_train: the GEMM k-order is identical, only
+    the per-tile partial sums differ in grouping (32- vs 64-row tiles), so gradients agree to a few fp32 ulps of their scale;
+    two runs of the fused path are bitwise equal (no float atomics)."""
+    pol = _policy(scale_heads=False)
+    k = MlpKernels(256, DEV, max_batch=8192)
+    k.pack(pol.flat)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    total, n = 30000, 8000          # ragged last tile (8000 = 250 * 32) and a gather
+    obs = torch.zeros((total, 64), device=DEV)
+    obs[:, :56] = torch.rand((total, 56), device=DEV, generator=g) * 2 - 1
+    act = torch.randn((total, 7), device=DEV, generator=g) * 0.5
+    old_logp = -7.0 + 0.3 * torch.randn(total, device=DEV, generator=g)
+    adv = torch.randn(total, device=DEV, generator=g)
+    ret = torch.randn(total, device=DEV, generator=g)
+    idx = torch.randperm(total, device=DEV, generator=g)[:n]
+    out = {}
+    for name, fused in (("fused", True), ("fused2", True), ("layer", False)):
+        k.set_fused(fused)
+        grad = torch.full((k.num_params,), float("nan"), device=DEV)
+        stats = torch.zeros(4, device=DEV)
+        k.loss_grad(obs, idx, n, act, old_logp, adv, ret, clip_range=0.2, ent_coef=1e-3, vf_coef=0.5, inv_count=1.0 / n, grad_out=grad, stats_out=stats)
+        out[name] = (grad.clone(), stats.clone())
+    assert torch.equal(out["fused"][0], out["fused2"][0]) and torch.equal(out["fused"][1], out["fused2"][1])
+    gf, gl = out["fused"][0], out["layer"][0]
+    assert torch.isfinite(gf).all()
+    off = 0
+    for name, shape in pol.spec:
+        cnt = math.prod(shape)
+        a, b = gf[off:off + cnt], gl[off:off + cnt]
+        scale = b.abs().max().item() + 1e-12
+        assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-9, name
+        off += cnt
+    assert torch.allclose(out["fused"][1], out["layer"][1], rtol=1e-5, atol=1e-6)
+    k.close()
+
+
 @pytest.mark.parametrize("n,stride", [(4096, 56), (4096, 64), (100, 56), (8192, 64), (12000, 64)])
 def test_mlp_forward_vs_torch(n, stride):
     pol = _policy()
@@ -59,10 +96,12 @@ def test_mlp_forward_vs_torch(n, stride):
     k.close()
 
 
-@pytest.mark.parametrize("n,total,gather", [(8192, 20000, True), (4096, 4096, False), (1000, 5000, True), (16384, 40000, True)])
-def test_mlp_loss_grad_vs_torch_autograd(n, total, gather):
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("n,total,gather", [(8192, 20000, True), (4096, 4096, False), (1000, 5000, True), (16384, 40000, True), (33, 64, True)])
+def test_mlp_loss_grad_vs_torch_autograd(n, total, gather, fused):
     pol = _policy(scale_heads=False)
     k = MlpKernels(256, DEV, max_batch=16384)
+    k.set_fused(fused)
     k.pack(pol.flat)
     g = torch.Generator(device=DEV).manual_seed(1)
     obs = torch.zeros((total, 64), device=DEV)
@@ -99,7 +138,8 @@ def test_mlp_loss_grad_vs_torch_autograd(n, total, gather):
     loss = pl + ent * (-entropy) + vf * vl
     (ref,) = torch.autograd.grad(loss, flat)
     frac_clipped = ((ratio - 1).abs() > clip).float().mean().item()
-    assert 0.02 < frac_clipped < 0.98          # both branches of the surrogate are exercised
+    if n >= 1000:
+        assert 0.02 < frac_clipped < 0.98      # both branches of the surrogate are exercised
     off = 0
     for name, shape in pol.spec:
         cnt = math.prod(shape)
