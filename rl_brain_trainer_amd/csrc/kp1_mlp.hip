@@ -664,10 +664,17 @@ __host__ __device__ inline ParamLayout make_layout(int H) {
 // row-major [N][K] layout a stage is N separate 128-byte pieces at a 1 KB pitch, which (256-byte channel interleave) land
 // on 4 of the 16 L2 channels of an XCD -- every CU streams the same stage at the same time, and the MFMA loops of all
 // three GEMM kinds sat at ~50 % waiting on those four channels.
+// The fused tile kernel reads a second copy, "fragment major": inside each 32-deep k stage the order is [MFMA column block
+// n/32][k group (k%32)/8][lane = n%32 + 32*((k%8)/4)][k%4] -- exactly the float4 every lane feeds to four consecutive
+// v_mfma_f32_32x32x2_f32 as B operand, so the weights go global -> VGPR in coalesced 1 KB wave loads, never through LDS.
 struct Packed {
   float *w1p, *b1, *w2, *w2t, *b2, *w3, *b3, *log_std;  // [2][2][Hp][32], [2][Hp], [2][Hp/32][Hp][32] x2, [2][Hp], [8][Hp], [8], [8]
+  float *w1f, *w2f, *w2tf;                               // fragment-major copies of w1p, w2, w2t
 };
 __host__ __device__ inline int64_t slab_at(int64_t n, int64_t k, int64_t N) { return (k >> 5) * N * 32 + n * 32 + (k & 31); }
+__host__ __device__ inline int64_t frag_at(int64_t n, int64_t k, int64_t N) {
+  return (k >> 5) * N * 32 + (n >> 5) * 1024 + ((k & 31) >> 3) * 256 + ((n & 31) + 32 * ((k & 7) >> 2)) * 4 + (k & 3);
+}
 
 // flat SB3 vector element i -> its place(s) in the kernel-format weights (zero padding pre-set once at creation)
 __device__ __forceinline__ void pack_one(int64_t i, float v, const ParamLayout& L, const Packed& k) {
@@ -677,23 +684,29 @@ __device__ __forceinline__ void pack_one(int64_t i, float v, const ParamLayout& 
   } else if (i < L.p_b1) {
     const int64_t e = i - L.p_w1;
     k.w1p[slab_at(e / IN, e % IN, Hp)] = v;
+    k.w1f[frag_at(e / IN, e % IN, Hp)] = v;
   } else if (i < L.p_w2) {
     k.b1[i - L.p_b1] = v;
   } else if (i < L.p_b2) {
     const int64_t e = i - L.p_w2, r = e / H, c = e % H;
     k.w2[slab_at(r, c, Hp)] = v;
     k.w2t[slab_at(c, r, Hp)] = v;
+    k.w2f[frag_at(r, c, Hp)] = v;
+    k.w2tf[frag_at(c, r, Hp)] = v;
   } else if (i < L.v_w1) {
     k.b2[i - L.p_b2] = v;
   } else if (i < L.v_b1) {
     const int64_t e = i - L.v_w1;
     k.w1p[(int64_t)Hp * INP + slab_at(e / IN, e % IN, Hp)] = v;
+    k.w1f[(int64_t)Hp * INP + frag_at(e / IN, e % IN, Hp)] = v;
   } else if (i < L.v_w2) {
     k.b1[Hp + i - L.v_b1] = v;
   } else if (i < L.v_b2) {
     const int64_t e = i - L.v_w2, r = e / H, c = e % H;
     k.w2[(int64_t)Hp * Hp + slab_at(r, c, Hp)] = v;
     k.w2t[(int64_t)Hp * Hp + slab_at(c, r, Hp)] = v;
+    k.w2f[(int64_t)Hp * Hp + frag_at(r, c, Hp)] = v;
+    k.w2tf[(int64_t)Hp * Hp + frag_at(c, r, Hp)] = v;
   } else if (i < L.a_w) {
     k.b2[Hp + i - L.v_b2] = v;
   } else if (i < L.a_b) {
@@ -744,52 +757,138 @@ __device__ __forceinline__ float sum_strided(const float* __restrict__ p, int64_
   return s;
 }
 
-__global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a) {
+// where the partials of flat gradient element i live: n values at p[c * stride], plus a constant
+struct PartialSrc {
+  const float* p; int64_t stride; int n; float add;
+  bool wide;  // few elements with one partial per 32-row tile (biases, heads, log_std): summed cooperatively
+};
+
+__device__ __forceinline__ PartialSrc finalize_source(const FinalizeArgs& a, int64_t i) {
   const ParamLayout& L = a.L;
   const int H = L.H, Hp = L.Hp;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  float gval = 0.f;
-  if (i < L.total) {
-    if (i < L.p_w1) {
-      gval = sum_strided<64>(a.hpart + 10 * Hp + 8 + i, a.h_stride, a.h_n) - a.ent_coef;  // d(-ent_coef * sum log_std)
-    } else if (i < L.p_b1 || (i >= L.v_w1 && i < L.v_b1)) {
-      const int net = i >= L.v_w1;
-      const int64_t e = i - (net ? L.v_w1 : L.p_w1);
-      gval = sum_strided<32>(a.slab1 + net * a.s1_net + (e / IN) * a.s1_ld + e % IN, a.s1_chunk, a.s1_n);
-    } else if (i < L.p_w2 || (i >= L.v_b1 && i < L.v_w2)) {
-      const int net = i >= L.v_b1;
-      gval = sum_strided<32>(a.bslab + net * a.b_net + (i - (net ? L.v_b1 : L.p_b1)), a.b_tile, a.b_n);
-    } else if (i < L.p_b2 || (i >= L.v_w2 && i < L.v_b2)) {
-      const int net = i >= L.v_w2;
-      const int64_t e = i - (net ? L.v_w2 : L.p_w2);
-      gval = sum_strided<16>(a.slab2 + net * a.s2_net + (e / H) * a.s2_ld + e % H, a.s2_chunk, a.s2_n);
-    } else if (i < L.v_w1) {
-      gval = sum_strided<64>(a.hpart + 8 * Hp + (i - L.p_b2), a.h_stride, a.h_n);
-    } else if (i < L.a_w) {
-      gval = sum_strided<64>(a.hpart + 9 * Hp + (i - L.v_b2), a.h_stride, a.h_n);
-    } else if (i < L.a_b) {
-      const int64_t e = i - L.a_w;
-      gval = sum_strided<64>(a.hpart + (e / H) * Hp + e % H, a.h_stride, a.h_n);
-    } else if (i < L.c_w) {
-      gval = sum_strided<64>(a.hpart + 10 * Hp + (i - L.a_b), a.h_stride, a.h_n);
-    } else if (i < L.c_b) {
-      gval = sum_strided<64>(a.hpart + 7 * Hp + (i - L.c_w), a.h_stride, a.h_n);
-    } else {
-      gval = sum_strided<64>(a.hpart + 10 * Hp + 7, a.h_stride, a.h_n);
-    }
-    a.grad[i] = gval;
+  PartialSrc r;
+  r.add = 0.f;
+  r.wide = true;
+  r.stride = a.h_stride;
+  r.n = a.h_n;
+  if (i < L.p_w1) {
+    r.p = a.hpart + 10 * Hp + 8 + i;
+    r.add = -a.ent_coef;  // d(-ent_coef * sum log_std)
+  } else if (i < L.p_b1 || (i >= L.v_w1 && i < L.v_b1)) {
+    const int net = i >= L.v_w1;
+    const int64_t e = i - (net ? L.v_w1 : L.p_w1);
+    r.p = a.slab1 + net * a.s1_net + (e / IN) * a.s1_ld + e % IN;
+    r.stride = a.s1_chunk; r.n = a.s1_n; r.wide = false;
+  } else if (i < L.p_w2 || (i >= L.v_b1 && i < L.v_w2)) {
+    const int net = i >= L.v_b1;
+    r.p = a.bslab + net * a.b_net + (i - (net ? L.v_b1 : L.p_b1));
+    r.stride = a.b_tile; r.n = a.b_n;
+  } else if (i < L.p_b2 || (i >= L.v_w2 && i < L.v_b2)) {
+    const int net = i >= L.v_w2;
+    const int64_t e = i - (net ? L.v_w2 : L.p_w2);
+    r.p = a.slab2 + net * a.s2_net + (e / H) * a.s2_ld + e % H;
+    r.stride = a.s2_chunk; r.n = a.s2_n; r.wide = false;
+  } else if (i < L.v_w1) {
+    r.p = a.hpart + 8 * Hp + (i - L.p_b2);
+  } else if (i < L.a_w) {
+    r.p = a.hpart + 9 * Hp + (i - L.v_b2);
+  } else if (i < L.a_b) {
+    const int64_t e = i - L.a_w;
+    r.p = a.hpart + (e / H) * Hp + e % H;
+  } else if (i < L.c_w) {
+    r.p = a.hpart + 10 * Hp + (i - L.a_b);
+  } else if (i < L.c_b) {
+    r.p = a.hpart + 7 * Hp + (i - L.c_w);
+  } else {
+    r.p = a.hpart + 10 * Hp + 7;
   }
-  if (a.stats && blockIdx.x == 0 && threadIdx.x < 3) {  // policy loss, value loss, approx kl (means over the minibatch)
-    const float v = sum_strided<64>(a.hpart + 10 * Hp + 15 + threadIdx.x, a.h_stride, a.h_n) * a.inv_count;
-    a.stats[threadIdx.x == 2 ? 3 : threadIdx.x] += v;  // single writer
-  }
-  if (a.step_counter && blockIdx.x == 0 && threadIdx.x == 4) *a.step_counter += 1;  // read by the adam kernel that follows
-  if (a.stats && blockIdx.x == 0 && threadIdx.x == 3) {  // entropy of the state-independent diagonal Gaussian
-    float ent = 0.f;
-    for (int k = 0; k < ACT; ++k) ent += 0.5f + LOG_SQRT_2PI + a.log_std[k];
-    a.stats[2] += ent;
-  }
+  return r;
+}
+
+// the "wide" elements in enumeration order: log_std, pi b1, pi b2, vf b1, vf b2, then everything from action_net on
+__host__ __device__ inline int64_t finalize_wide_count(const ParamLayout& L) { return ACT + 4 * (int64_t)L.H + (L.total - L.a_w); }
+__device__ __forceinline__ int64_t finalize_wide_index(const ParamLayout& L, int64_t e) {
+  const int H = L.H;
+  if (e < ACT) return L.log_std + e;
+  e -= ACT;
+  if (e < H) return L.p_b1 + e;
+  e -= H;
+  if (e < H) return L.p_b2 + e;
+  e -= H;
+  if (e < H) return L.v_b1 + e;
+  e -= H;
+  if (e < H) return L.v_b2 + e;
+  e -= H;
+  return L.a_w + e;
+}
+
+// Blocks [0, n_main): one thread per flat element; the weight matrices (few partials per element: one per batch chunk of
+// the TN GEMMs) are summed by their thread, "wide" elements are skipped.  Blocks [n_main, ...): 32 wide elements each, 8
+// threads per element walk the per-tile partials with a stride of 8 (32 loads in flight each) and LDS combines the 8
+// strands in a fixed order -- a single thread summing 256 tiles was the tail of this kernel (8 dependent load rounds).
+// Every block leaves the sum of squares of what it wrote in sumsq[blockIdx.x] for clip_grad_norm_.
+__global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a, int n_main) {
+  const ParamLayout& L = a.L;
   __shared__ double sq[256];
+  __shared__ float red[8][32];
+  float gval = 0.f;
+  if ((int)blockIdx.x < n_main) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < L.total) {
+      const PartialSrc s = finalize_source(a, i);
+      if (!s.wide) {
+        gval = sum_strided<32>(s.p, s.stride, s.n);
+        a.grad[i] = gval;
+      }
+    }
+    if (a.step_counter && blockIdx.x == 0 && threadIdx.x == 0) *a.step_counter += 1;  // read by the adam kernel that follows
+    if (a.stats && blockIdx.x == 0 && threadIdx.x == 3) {  // entropy of the state-independent diagonal Gaussian
+      float ent = 0.f;
+      for (int k = 0; k < ACT; ++k) ent += 0.5f + LOG_SQRT_2PI + a.log_std[k];
+      a.stats[2] += ent;
+    }
+  } else {
+    const int64_t n_wide = finalize_wide_count(L);
+    const int el = threadIdx.x & 31, strand = threadIdx.x >> 5;
+    const int64_t e = (int64_t)(blockIdx.x - n_main) * 32 + el;
+    // elements n_wide .. n_wide+2 are the three loss sums (policy, value, kl), not gradients
+    const bool is_grad = e < n_wide, is_stat = !is_grad && e < n_wide + 3;
+    PartialSrc s{};
+    int64_t flat = 0;
+    if (is_grad) {
+      flat = finalize_wide_index(L, e);
+      s = finalize_source(a, flat);
+    } else if (is_stat) {
+      s.p = a.hpart + 10 * L.Hp + 15 + (e - n_wide);
+      s.stride = a.h_stride; s.n = a.h_n; s.add = 0.f;
+    }
+    float part = 0.f;
+    if (is_grad || is_stat) {
+      int c = strand;
+      for (; c + 8 * 31 < s.n; c += 8 * 32) {
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = s.p[(int64_t)(c + 8 * u) * s.stride];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) part += v[u];
+      }
+      for (; c < s.n; c += 8) part += s.p[(int64_t)c * s.stride];
+    }
+    red[strand][el] = part;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      float t = red[0][el];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) t += red[k][el];
+      if (is_grad) {
+        gval = t + s.add;
+        a.grad[flat] = gval;
+      } else if (is_stat && a.stats) {
+        const int k = (int)(e - n_wide);
+        a.stats[k == 2 ? 3 : k] += t * a.inv_count;  // single writer
+      }
+    }
+  }
   sq[threadIdx.x] = (double)gval * (double)gval;
   __syncthreads();
   for (int k = 128; k > 0; k >>= 1) {
@@ -1019,6 +1118,9 @@ int kp1_mlp_create(int32_t device, int32_t hidden, int32_t max_batch, kp1_mlp** 
   MLP_ALLOC(m->k.b1, 2 * Hp);
   MLP_ALLOC(m->k.w2, 2 * Hp * Hp);
   MLP_ALLOC(m->k.w2t, 2 * Hp * Hp);
+  MLP_ALLOC(m->k.w1f, 2 * Hp * INP);
+  MLP_ALLOC(m->k.w2f, 2 * Hp * Hp);
+  MLP_ALLOC(m->k.w2tf, 2 * Hp * Hp);
   MLP_ALLOC(m->k.b2, 2 * Hp);
   MLP_ALLOC(m->k.w3, HEADS * Hp);
   MLP_ALLOC(m->k.b3, HEADS);
@@ -1183,9 +1285,10 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   f.ent_coef = ent_coef; f.inv_count = inv_count; f.log_std = m->k.log_std;
   f.grad = grad_out; f.stats = stats_out; f.sumsq = m->partials + 2 * N_PARTIALS;
   f.step_counter = m->step_dev;
-  m->n_finalize_blocks = (int)((L.total + 255) / 256);
+  const int n_main = (int)((L.total + 255) / 256);
+  m->n_finalize_blocks = n_main + (int)((finalize_wide_count(L) + 3 + 31) / 32);
   if (m->n_finalize_blocks > 2048) return fail(KP1_ERR_INVALID, "parameter vector too large for the sum-of-squares partial buffer");
-  hipLaunchKernelGGL(grad_finalize_kernel, dim3(m->n_finalize_blocks), dim3(256), 0, stream, f);
+  hipLaunchKernelGGL(grad_finalize_kernel, dim3(m->n_finalize_blocks), dim3(256), 0, stream, f, n_main);
   HIP_TRY(hipGetLastError());
   return KP1_OK;
 }

@@ -67,6 +67,9 @@ if fused:
         d = np.diff(sel[:, :7], axis=1)
         print(f"net {zz}: per-phase medians (prologue, G1+tanh, G2+tanh, heads, G3+dtanh, store):", np.round(np.median(d, axis=0), 2),
               " first-round workgroups:", int((sel[:, 0] < 1.0).sum()))
+    if (t[:, 7] > 0).any():
+        g2 = us[:, [2] + list(range(7, 15))]
+        print("G2 per-stage medians (wave 0 of each workgroup, us):", np.round(np.median(np.diff(g2, axis=1), axis=0), 2))
     sys.exit(0)
 names = ["start", "prologue_done"] + [f"stages_{2 * i}-{2 * i + 1}_done" for i in range(8)] + ["acc_in_lds", "stores_issued"]
 for i, nm in enumerate(names):
