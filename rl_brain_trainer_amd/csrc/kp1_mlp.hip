@@ -318,10 +318,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
       for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
 
   const int KT = (b_end - b_begin + TB - 1) / TB;
+  KP1_TR(0)
   if (KT > 0) {  // uniform per workgroup
     KP1_TN_LOAD(b_begin)
     KP1_TN_STORE(0, b_begin)
     __syncthreads();
+    KP1_TR(1)
     for (int kt = 0; kt < KT; ++kt) {
       const int buf = kt & 1;
       KP1_TN_LOAD(b_begin + (kt + 1) * TB)  // past the chunk end: clamped rows, zeroed at store time
@@ -347,6 +349,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
       }
       KP1_TN_STORE(buf ^ 1, b_begin + (kt + 1) * TB)
       __syncthreads();
+      KP1_TR(2 + (kt < 8 ? kt : 8))
     }
   }
 #undef KP1_TN_LOAD
@@ -364,6 +367,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
         Ps[o * LDP + wc * 64 + 2 * (lane & 31) + c] = acc[r][c][e];
       }
   __syncthreads();
+  KP1_TR(11)
   float* __restrict__ P = g.slab + blockIdx.x * g.slab_chunk_stride + z * g.slab_net_stride;
 #pragma unroll
   for (int j = 0; j < TT * TT / 4 / 256; ++j) {
@@ -371,6 +375,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     const int col = i0 + 4 * q;
     if (col < g.slab_ld) *reinterpret_cast<f32x4*>(P + (int64_t)(o0 + o) * g.slab_ld + col) = *reinterpret_cast<const f32x4*>(Ps + o * LDP + 4 * q);
   }
+  KP1_TR(12)
 }
 
 // ---------------------------------------------------------------------------------------------- heads
@@ -961,6 +966,7 @@ struct kp1_mlp {
   float* h2 = nullptr;
   float* dz2 = nullptr;
   float* dz1 = nullptr;
+  float* xf = nullptr;    // [max_batch][64] gathered observations, k8-fragment major (fused path)
   double* partials = nullptr;  // [512]
   float* slab = nullptr;       // [64 chunks][2 nets][Hp][Hp] partial dW2
   float* slab1 = nullptr;      // [64 chunks][2 nets][Hp][64] partial dW1
@@ -1037,6 +1043,14 @@ int launch_fused(const FusedArgs& fa, hipStream_t stream) {
   const size_t bytes = sizeof(float) * FU_LDS_FLOATS;
   HIP_TRY(hipFuncSetAttribute((const void*)mlp_train_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   hipLaunchKernelGGL(mlp_train_tile_kernel, dim3((fa.n + FU_BM - 1) / FU_BM, 1, 2), dim3(FU_NTH), bytes, stream, fa);
+  return KP1_OK;
+}
+
+int launch_tn_frag(const TnFragArgs& t, hipStream_t stream) {
+  if (t.n_chunks2 > 64 || t.n_chunks1 > 64) return fail(KP1_ERR_INVALID, "too many batch chunks for the partial-gradient slabs");
+  const size_t bytes = sizeof(float) * 128 * (128 + 4);
+  HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_frag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  hipLaunchKernelGGL(gemm_tn_frag_kernel, dim3(8 * t.n_chunks2 + 4 * t.n_chunks1), dim3(256), bytes, stream, t);
   return KP1_OK;
 }
 
@@ -1129,6 +1143,7 @@ int kp1_mlp_create(int32_t device, int32_t hidden, int32_t max_batch, kp1_mlp** 
   MLP_ALLOC(m->h2, 2 * mb * Hp);
   MLP_ALLOC(m->dz2, 2 * mb * Hp);
   MLP_ALLOC(m->dz1, 2 * mb * Hp);
+  MLP_ALLOC(m->xf, mb * INP);
   MLP_ALLOC(m->partials, 2 * N_PARTIALS + 2048);
   MLP_ALLOC(m->slab, (int64_t)64 * 2 * Hp * Hp);
   MLP_ALLOC(m->slab1, (int64_t)64 * 2 * Hp * INP);
@@ -1218,7 +1233,7 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
     fa.adv_partials = m->partials; fa.n_adv_partials = N_PARTIALS; fa.adv_stats = adv_stats_dev; fa.adv_mean = adv_mean; fa.adv_inv_std = adv_inv_std;
     fa.adv_mode = adv_mode;
     fa.clip_range = clip_range; fa.vf_coef = vf_coef; fa.inv_count = inv_count;
-    fa.h1 = m->h1; fa.dz2 = m->dz2; fa.dz1 = m->dz1; fa.act_stride = act_stride;
+    fa.h1 = m->h1; fa.dz2 = m->dz2; fa.dz1 = m->dz1; fa.act_stride = act_stride; fa.xf = m->xf;
     fa.bslab = m->bslab; fa.hpart = m->hpart; fa.hpart_stride = hpart_stride;
     rc = launch_fused(fa, stream);
     if (rc != KP1_OK) return rc;
@@ -1259,23 +1274,40 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   }
 
   // weight gradients (split over the batch axis)
-  GemmTN t{};
-  t.B = n;
-  t.chunk = tn_chunk_rows(n, (Hp / 128) * (Hp / 128) * 2);
-  // dW2[o][i] = sum_b dZ2[b][o] h1[b][i]
-  t.D = m->dz2; t.ldd = Hp; t.strideD = act_stride;
-  t.X = m->h1; t.ldx = Hp; t.strideX = act_stride; t.gatherX = nullptr;
-  t.Nload = Hp; t.n_i_tiles = Hp / 128;
   int s2_n = 0, s1_n = 0;
-  rc = launch_tn(m, t, Hp / 128, Hp, m->slab, &s2_n, stream);
-  if (rc != KP1_OK) return rc;
-  // dW1[o][i] = sum_b dZ1[b][o] x[b][i]   (i < 56)
-  t.D = m->dz1;
-  t.X = obs; t.ldx = obs_stride; t.strideX = 0; t.gatherX = idx;
-  t.Nload = obs_stride >= INP ? INP : IN; t.n_i_tiles = 1;
-  t.chunk = tn_chunk_rows(n, (Hp / 128) * 2);  // few tiles: more, shorter batch chunks keep the CUs busy
-  rc = launch_tn(m, t, Hp / 128, INP, m->slab1, &s1_n, stream);
-  if (rc != KP1_OK) return rc;
+  if (fused) {
+    TnFragArgs t{};
+    t.dz2 = m->dz2; t.h1 = m->h1; t.dz1 = m->dz1; t.act_stride = act_stride; t.xf = m->xf;
+    t.slab2 = m->slab; t.s2_net = (int64_t)Hp * Hp; t.s2_chunk = 2 * t.s2_net;
+    t.slab1 = m->slab1; t.s1_net = (int64_t)Hp * INP; t.s1_chunk = 2 * t.s1_net;
+    t.groups = (n + FU_BM - 1) / FU_BM * (FU_BM / 8);
+    auto up8 = [](int v) { return (v + 7) / 8 * 8; };
+    t.cg2 = up8((t.groups + 31) / 32);   // ~32 chunks x 8 tiles = one dW2 workgroup per CU
+    t.cg1 = up8((t.groups + 63) / 64);   // ~64 chunks x 4 tiles of quarter-size dW1 workgroups
+    t.n_chunks2 = (t.groups + t.cg2 - 1) / t.cg2;
+    t.n_chunks1 = (t.groups + t.cg1 - 1) / t.cg1;
+    rc = launch_tn_frag(t, stream);
+    if (rc != KP1_OK) return rc;
+    s2_n = t.n_chunks2;
+    s1_n = t.n_chunks1;
+  } else {
+    GemmTN t{};
+    t.B = n;
+    t.chunk = tn_chunk_rows(n, (Hp / 128) * (Hp / 128) * 2);
+    // dW2[o][i] = sum_b dZ2[b][o] h1[b][i]
+    t.D = m->dz2; t.ldd = Hp; t.strideD = act_stride;
+    t.X = m->h1; t.ldx = Hp; t.strideX = act_stride; t.gatherX = nullptr;
+    t.Nload = Hp; t.n_i_tiles = Hp / 128;
+    rc = launch_tn(m, t, Hp / 128, Hp, m->slab, &s2_n, stream);
+    if (rc != KP1_OK) return rc;
+    // dW1[o][i] = sum_b dZ1[b][o] x[b][i]   (i < 56)
+    t.D = m->dz1;
+    t.X = obs; t.ldx = obs_stride; t.strideX = 0; t.gatherX = idx;
+    t.Nload = obs_stride >= INP ? INP : IN; t.n_i_tiles = 1;
+    t.chunk = tn_chunk_rows(n, (Hp / 128) * 2);  // few tiles: more, shorter batch chunks keep the CUs busy
+    rc = launch_tn(m, t, Hp / 128, INP, m->slab1, &s1_n, stream);
+    if (rc != KP1_OK) return rc;
+  }
   FinalizeArgs f{};
   f.L = L;
   f.slab2 = m->slab; f.s2_ld = Hp; f.s2_net = (int64_t)Hp * Hp; f.s2_chunk = 2 * f.s2_net; f.s2_n = s2_n;

@@ -10,6 +10,32 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// NACC independent accumulator chains per wave (2 = a 32x64 wave tile, 4 = a 64x64 wave tile)
+template <int NACC>
+__global__ void __launch_bounds__(512) burn_n(float* out, unsigned long long* clk, int iters, float seed) {
+  f32x16 a[NACC];
+  for (int k = 0; k < NACC; ++k)
+    for (int e = 0; e < 16; ++e) a[k][e] = 0.f;
+  float x[4], y[4];
+  for (int k = 0; k < 4; ++k) {
+    x[k] = seed + threadIdx.x * 1e-3f + k;
+    y[k] = 1.f - threadIdx.x * 2e-3f - k;
+  }
+  const unsigned long long w0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 16 / NACC; ++u)
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) a[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[(u + k) & 3], y[k & 3], a[k], 0, 0, 0);
+  }
+  const unsigned long long w1 = wall_clock64();
+  float s = 0.f;
+  for (int k = 0; k < NACC; ++k)
+    for (int e = 0; e < 16; ++e) s += a[k][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) clk[2 * blockIdx.x] = w1 - w0;
+}
+
 __global__ void __launch_bounds__(512) burn(float* out, unsigned long long* clk, int iters, float seed) {
   f32x16 a0, a1;
   for (int e = 0; e < 16; ++e) {
@@ -68,6 +94,27 @@ int main() {
                  threads / 64, mfma_per_simd, ms * 1e3, flops / (ms * 1e-3) / 1e12, wall / 100.0, flops / (wall * 1e-8) / 1e12, cyc / wall,
                  wall * 10.0 / mfma_per_simd);
       }
+    }
+  }
+  // accumulator-count sweep at a GEMM-phase-sized burst (512 MFMAs per SIMD)
+  for (int threads : {256, 512}) {
+    for (int nacc : {1, 2, 4, 8}) {
+      const int iters = threads == 256 ? 32 : 16;
+      for (int rep = 0; rep < 3; ++rep) {
+        if (nacc == 1) hipLaunchKernelGGL(burn_n<1>, dim3(256), dim3(threads), 0, 0, out, clk, iters, 0.5f);
+        if (nacc == 2) hipLaunchKernelGGL(burn_n<2>, dim3(256), dim3(threads), 0, 0, out, clk, iters, 0.5f);
+        if (nacc == 4) hipLaunchKernelGGL(burn_n<4>, dim3(256), dim3(threads), 0, 0, out, clk, iters, 0.5f);
+        if (nacc == 8) hipLaunchKernelGGL(burn_n<8>, dim3(256), dim3(threads), 0, 0, out, clk, iters, 0.5f);
+        hipDeviceSynchronize();
+      }
+      std::vector<unsigned long long> h(512);
+      hipMemcpy(h.data(), clk, sizeof(unsigned long long) * 512, hipMemcpyDeviceToHost);
+      double wall = 0;
+      for (int b = 0; b < 256; ++b) wall += h[2 * b];
+      wall /= 256;
+      const double mfma_per_simd = (threads / 256.0) * iters * 16.0;
+      printf("accumulators/wave %d  waves/CU %d  mfma/SIMD %4.0f  in-kernel %7.2f us  -> %.1f ns per MFMA per SIMD\n", nacc, threads / 64, mfma_per_simd,
+             wall / 100.0, wall * 10.0 / mfma_per_simd);
     }
   }
   return 0;

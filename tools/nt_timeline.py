@@ -6,6 +6,7 @@ the first workgroup's start: when workgroups start, how long the prologue, each 
 
     python tools/nt_timeline.py [rows]            # layer-wise gemm_nt (the last NT launch of time_kernels = bwd dZ1)
     python tools/nt_timeline.py [rows] fused      # mlp_train_tile_kernel (one loss_grad call)
+    python tools/nt_timeline.py [rows] tnfrag     # gemm_tn_frag_kernel (the launch after it in the same loss_grad call)
 """
 import ctypes as C
 import os
@@ -18,7 +19,8 @@ out_dir = os.path.join(ROOT, "gpurun_out")
 os.makedirs(out_dir, exist_ok=True)
 lib = os.path.join(out_dir, "libkp1_trace.so")
 srcs = [os.path.join(ROOT, "rl_brain_trainer_amd/csrc", f) for f in ("kp1_env.hip", "kp1_ppo.hip", "kp1_mlp.hip")]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DKP1_NT_TRACE", "-shared", "-o", lib] + srcs)
+extra = [f"-D{d}" for d in os.environ.get("KP1_TRACE_DEFS", "").split() if d]   # e.g. KP1_TNF_NOMFMA, KP1_TNF_NOLOAD
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DKP1_NT_TRACE", "-shared", "-o", lib] + extra + srcs)
 
 import numpy as np
 import torch
@@ -39,6 +41,9 @@ obs[:, :56] = torch.rand((n, 56), device=dev) * 2 - 1
 L = native.load()
 L.kp1_debug_nt_trace.argtypes = [C.c_void_p, C.c_int]
 fused = len(sys.argv) > 2 and sys.argv[2] == "fused"
+tn = len(sys.argv) > 2 and sys.argv[2] == "tn"
+tnfrag = len(sys.argv) > 2 and sys.argv[2] == "tnfrag"
+fused = fused or tnfrag
 if fused:
     act = torch.randn((n, 7), device=dev)
     z = torch.zeros(n, device=dev)
@@ -48,15 +53,30 @@ if fused:
                     grad_out=grad, stats_out=None)
     torch.cuda.synchronize()
 else:
-    k.time_kernels(obs, n, iters=3)
+    k.time_kernels(obs, n, iters=3)   # last launch = gemm_tn dW2
 buf = np.zeros(16 * 1024, dtype=np.uint64)
 # time_kernels runs layer 1 (64-deep) first, then fwd L2, then bwd: the buffer holds the LAST NT launch = bwd dZ1
 L.kp1_debug_nt_trace(buf.ctypes.data, 0)
 t = buf.reshape(1024, 16).astype(np.int64)
-t = t[t[:, 0] > 0]
-t0 = t[:, 0].min()
+base = 12 if tnfrag else 0      # the TN-frag launch stamps slots 12..15, everything else starts at slot 0
+t = t[t[:, base] > 0]
+t0 = t[:, base].min()
 us = (t - t0) / 100.0
 print("workgroups traced:", len(t))
+if tnfrag:
+    # the tile kernel's stamps are overwritten by the TN launch that follows it (same buffer, block-linear index)
+    for nm, sel in (("dW2 workgroups", us[:256]), ("dW1 workgroups", us[256:512])):
+        print(nm, "start / loop done / acc in LDS / stored (median us):", np.round(np.median(sel[:, 12:16], axis=0), 2),
+              " max stored", round(float(sel[:, 15].max()), 2), " latest start", round(float(sel[:, 12].max()), 2))
+    sys.exit(0)
+if tn:
+    names = ["start", "stage0_in_lds", "st0", "st1", "st2", "st3", "st4", "st5", "st6", "st7", "st8+", "acc_in_lds", "stores_issued"]
+    for i, nm in enumerate(names):
+        if (t[:, i] == 0).all():
+            continue
+        col = us[:, i]
+        print(f"{nm:>18}: min {col.min():7.2f}  median {np.median(col):7.2f}  max {col.max():7.2f}")
+    sys.exit(0)
 if fused:
     names = ["start", "prologue_done", "h1_in_lds", "h2_in_lds", "heads_done", "dz1_in_lds", "stores_issued"]
     for i, nm in enumerate(names):
