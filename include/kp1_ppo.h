@@ -33,6 +33,13 @@ int kp1_gae_scan(int32_t device, const float* rewards, const float* values, cons
 int kp1_bootstrap_truncated(int32_t device, float* rewards, const float* terminal_values, const uint8_t* dones, float gamma,
                             int64_t count, void* stream);
 
+/* Advantage statistics of every minibatch of an epoch in ONE launch (SB3 normalises per minibatch: ppo.py train(),
+ * advantages = (adv - adv.mean()) / (adv.std() + 1e-8)).  Minibatch b = idx[b*minibatch .. min((b+1)*minibatch, total)) (idx NULL =
+ * identity).  out_sums f64 [n_minibatches][3] = (sum, sum of squares, count): the host side (or, data parallel, ONE all-reduce per
+ * epoch instead of one per minibatch) turns them into (mean, 1/(std+1e-8)) for kp1_mlp_loss_grad's adv_stats_dev. */
+int kp1_adv_minibatch_sums(int32_t device, const float* advantages, const int64_t* idx, int64_t total, int64_t minibatch, double* out_sums,
+                           void* stream);
+
 /* ---- device-resident PointCurriculumCallback (kinematic_phase1/training/callbacks.py:32-101) --------------------
  * The callback scans (done, info["success"]) in env order after every VecEnv step and may promote the stage for ALL
  * envs; resets inside that step already happened with the old stage.  Keeping the tracker on the device removes the

@@ -158,6 +158,52 @@ int kp1_gae_scan(int32_t device, const float* rewards, const float* values, cons
   return KP1_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// (sum, sum of squares) of the advantages of every minibatch of an epoch in one launch: block b covers
+// idx[b * mb .. min((b + 1) * mb, total)).  fp64, fixed summation order => deterministic.
+__global__ void __launch_bounds__(256) adv_minibatch_sums_kernel(const float* __restrict__ adv, const int64_t* __restrict__ idx, int64_t total, int64_t mb,
+                                                                 double* __restrict__ out) {
+  __shared__ double s1[256], s2[256];
+  const int64_t begin = (int64_t)blockIdx.x * mb, end = begin + mb < total ? begin + mb : total;
+  double a = 0.0, b = 0.0;
+  for (int64_t i = begin + threadIdx.x; i < end; i += 256) {
+    const double v = (double)adv[idx ? idx[i] : i];
+    a += v;
+    b += v * v;
+  }
+  s1[threadIdx.x] = a;
+  s2[threadIdx.x] = b;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) {
+      s1[threadIdx.x] += s1[threadIdx.x + k];
+      s2[threadIdx.x] += s2[threadIdx.x + k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[3 * blockIdx.x] = s1[0];
+    out[3 * blockIdx.x + 1] = s2[0];
+    out[3 * blockIdx.x + 2] = (double)(end - begin);
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int kp1_adv_minibatch_sums(int32_t device, const float* advantages, const int64_t* idx, int64_t total, int64_t minibatch, double* out_sums,
+                           void* stream) {
+  if (!advantages || !out_sums || total <= 0 || minibatch <= 0) return fail(KP1_ERR_INVALID, "bad argument to kp1_adv_minibatch_sums");
+  int rc = check_device(device);
+  if (rc != KP1_OK) return rc;
+  const int64_t n_mb = (total + minibatch - 1) / minibatch;
+  hipLaunchKernelGGL(adv_minibatch_sums_kernel, dim3((unsigned)n_mb), dim3(256), 0, (hipStream_t)stream, advantages, idx, total, minibatch, out_sums);
+  HIP_TRY(hipGetLastError());
+  return KP1_OK;
+}
+
 int kp1_bootstrap_truncated(int32_t device, float* rewards, const float* terminal_values, const uint8_t* dones, float gamma, int64_t count,
                             void* stream) {
   if (!rewards || !terminal_values || !dones || count <= 0) return fail(KP1_ERR_INVALID, "bad argument to kp1_bootstrap_truncated");

@@ -334,8 +334,10 @@ class PPO:
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(self.device)
         with torch.cuda.graph(g):
-            for start in range(0, total, local_bs):
-                self._hip_minibatch_step(obs, self.perm[start:start + local_bs], act, old_logp, adv, ret, device_step=True)
+            mb_stats = self._epoch_adv_stats(adv, self.perm, total, local_bs)
+            for i, start in enumerate(range(0, total, local_bs)):
+                self._hip_minibatch_step(obs, self.perm[start:start + local_bs], act, old_logp, adv, ret, device_step=True,
+                                         adv_stats=None if mb_stats is None else mb_stats[i])
         self._epoch_graph = g
 
     # ------------------------------------------------------------------ update
@@ -360,8 +362,10 @@ class PPO:
                 if self._epoch_graph is None:
                     # one eager epoch first (warm-up + it is a real epoch), then capture for the following ones
                     if _epoch == 0 and self.adam_t == 0:
-                        for start in range(0, total, local_bs):
-                            self._hip_minibatch_step(obs, self.perm[start:start + local_bs], act, old_logp, adv, ret, device_step=True)
+                        mb_stats = self._epoch_adv_stats(adv, self.perm, total, local_bs)
+                        for i, start in enumerate(range(0, total, local_bs)):
+                            self._hip_minibatch_step(obs, self.perm[start:start + local_bs], act, old_logp, adv, ret, device_step=True,
+                                                     adv_stats=None if mb_stats is None else mb_stats[i])
                             n_updates += 1
                             self.adam_t += 1
                         continue
@@ -371,10 +375,11 @@ class PPO:
                 self.adam_t += (total + local_bs - 1) // local_bs
                 continue
             perm = torch.randperm(total, device=self.device, generator=self.gen)
-            for start in range(0, total, local_bs):
+            mb_stats = self._epoch_adv_stats(adv, perm, total, local_bs) if self._mlp is not None else None
+            for i, start in enumerate(range(0, total, local_bs)):
                 idx = perm[start:start + local_bs]
                 if self._mlp is not None:
-                    self._hip_minibatch_step(obs, idx, act, old_logp, adv, ret)
+                    self._hip_minibatch_step(obs, idx, act, old_logp, adv, ret, adv_stats=None if mb_stats is None else mb_stats[i])
                 else:
                     stats += self._minibatch_step(obs[idx], act[idx], old_logp[idx], adv[idx], ret[idx])
                 n_updates += 1
@@ -383,13 +388,31 @@ class PPO:
         self.last_stats = dict(zip(("policy_loss", "value_loss", "entropy", "approx_kl"), (stats / max(n_updates, 1)).tolist()))
         self.last_stats["n_updates"] = n_updates
 
-    def _hip_minibatch_step(self, obs, idx, act, old_logp, adv, ret, device_step: bool = False) -> None:
+    def _epoch_adv_stats(self, adv, perm, total: int, local_bs: int):
+        """(mean, 1/(std + 1e-8)) of the advantages of every minibatch of this epoch, f32 [n_minibatches, 2] on the device.
+
+        SB3 normalises per minibatch (ppo.py train()).  One kernel sums all minibatches, and with data parallelism ONE
+        all-reduce per epoch makes the statistics those of the global minibatch (all ranks' shards together), so the
+        update does not depend on how the rollout is sharded -- instead of a 3-float collective before every optimiser step."""
+        if not self.cfg.normalize_advantage:
+            return None
+        n_mb = (total + local_bs - 1) // local_bs
+        sums = torch.empty((n_mb, 3), dtype=torch.float64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        native.check(self.L.kp1_adv_minibatch_sums(self.device.index or 0, C.c_void_p(adv.data_ptr()), C.c_void_p(perm.data_ptr()), total, local_bs,
+                                                   C.c_void_p(sums.data_ptr()), C.c_void_p(stream)))
+        self.dist.all_reduce_sum(sums)
+        cnt = sums[:, 2]
+        mean = sums[:, 0] / cnt
+        var = ((sums[:, 1] - cnt * mean * mean) / (cnt - 1.0).clamp_min(1.0)).clamp_min(0.0)
+        return torch.stack([mean, 1.0 / (var.sqrt() + 1e-8)], dim=1).float().contiguous()
+
+    def _hip_minibatch_step(self, obs, idx, act, old_logp, adv, ret, device_step: bool = False, adv_stats=None) -> None:
         """one optimiser step, all on the device: gathered fwd + loss + bwd (MFMA), flat grad all-reduce, clip + Adam + repack"""
         cfg = self.cfg
         n = int(idx.numel())
         world = self.dist.world_size
-        adv_stats = None
-        if cfg.normalize_advantage and self.dist.enabled:
+        if adv_stats is None and cfg.normalize_advantage and self.dist.enabled:
             mean, inv_std = global_advantage_stats(adv[idx], self.dist)
             adv_stats = torch.stack([mean, inv_std]).float()
         self._mlp.loss_grad(obs, idx, n, act, old_logp, adv, ret, clip_range=cfg.clip_range, ent_coef=cfg.ent_coef / world, vf_coef=cfg.vf_coef,

@@ -237,3 +237,25 @@ def test_device_curriculum_matches_golden_tracker():
         ends = [min(s + 7, len(seq)) - 1 for s in range(0, len(seq), 7)]
         assert stages == [case["stage_after"][e] for e in ends]
         cur.close()
+
+
+def test_adv_minibatch_sums_vs_torch():
+    """per-epoch advantage statistics: every minibatch's (sum, sum^2, count) in one launch, ragged last minibatch included"""
+    import ctypes as C
+
+    from rl_brain_trainer_amd import native
+
+    L = native.load()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    total, mb = 10000, 3000
+    adv = torch.randn(total, device=DEV, generator=g) * 2 + 0.3
+    perm = torch.randperm(total, device=DEV, generator=g)
+    n_mb = (total + mb - 1) // mb
+    out = torch.zeros((n_mb, 3), dtype=torch.float64, device=DEV)
+    native.check(L.kp1_adv_minibatch_sums(0, C.c_void_p(adv.data_ptr()), C.c_void_p(perm.data_ptr()), total, mb, C.c_void_p(out.data_ptr()),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    for b in range(n_mb):
+        sel = adv[perm[b * mb:(b + 1) * mb]].double()
+        assert out[b, 2].item() == sel.numel()
+        assert abs(out[b, 0].item() - sel.sum().item()) <= 1e-9 * sel.abs().sum().item()
+        assert abs(out[b, 1].item() - (sel * sel).sum().item()) <= 1e-9 * (sel * sel).sum().item()
