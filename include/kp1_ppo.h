@@ -112,9 +112,10 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
                       float* stats_out, int32_t grad_is_zero, void* stream);
 
 /* Options.  KP1_MLP_OPT_FUSED (default 1): for hidden = 256, kp1_mlp_loss_grad runs layer 1, layer 2, the heads, the PPO loss
- * and the activation backward of a 32-row minibatch tile in one workgroup (mlp_train_tile_kernel) instead of four
- * chip-synchronous launches; 0 selects the layer-wise kernels (always used for hidden = 128).  Same results up to fp32
- * summation order of the per-tile partials. */
+ * and the activation backward of a 32-row minibatch tile in one workgroup (mlp_tile_kernel<true>) instead of four
+ * chip-synchronous launches, and kp1_mlp_forward runs layer 1, layer 2, the heads and the Gaussian sampling in one launch
+ * (mlp_tile_kernel<false>) instead of three; 0 selects the layer-wise kernels (always used for hidden = 128).  Same results up
+ * to fp32 summation order of the per-tile partials. */
 #define KP1_MLP_OPT_FUSED 1
 int kp1_mlp_set_option(kp1_mlp* m, int32_t option, int32_t value);
 
@@ -125,11 +126,13 @@ int kp1_mlp_set_option(kp1_mlp* m, int32_t option, int32_t value);
 int kp1_mlp_adam_step(kp1_mlp* m, float* params, float* grad, float* exp_avg, float* exp_avg_sq, float lr, float eps,
                       float max_grad_norm, int32_t step, int32_t flags, void* stream);
 
-/* HIP-event timing of the three MFMA GEMM kernels at minibatch size n (for bench.py's roofline block): runs each kernel
- * `iters` times back to back on `stream` between hipEventRecord pairs and returns the mean duration in milliseconds:
- *   out_ms[0] gemm_nt fwd layer 2 (H x H, bias+tanh)   out_ms[1] gemm_nt bwd dZ1 (H x H, dtanh)
- *   out_ms[2] gemm_tn dW2 (H x H, split over the batch) out_ms[3] gemm_nt fwd layer 1 (64 -> H)
- * out_flops[k] = algorithmic FLOPs of one launch of kernel k (2*M*N*K summed over both nets). */
+/* HIP-event timing of the MFMA kernels at minibatch size n (for bench.py's roofline block): runs each kernel `iters` times back
+ * to back on `stream` between hipEventRecord pairs and returns the mean duration in milliseconds (out_ms / out_flops hold 6):
+ *   out_ms[0] gemm_nt fwd layer 2 (H x H, bias+tanh)    out_ms[1] gemm_nt bwd dZ1 (H x H, dtanh)
+ *   out_ms[2] gemm_tn dW2 (H x H, split over the batch)  out_ms[3] gemm_nt fwd layer 1 (64 -> H)
+ *   out_ms[4] mlp_tile_kernel<true> (hidden 256: layer 1 + layer 2 + heads + loss + activation backward of both nets)
+ *   out_ms[5] gemm_tn_frag_kernel (hidden 256: dW2 + dW1 of both nets)          [4], [5] = 0 for other widths
+ * out_flops[k] = algorithmic FLOPs of one launch of kernel k (2*M*N*K summed over its GEMMs and both nets). */
 int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32_t n, int32_t iters, float* out_ms, double* out_flops,
                          void* stream);
 

@@ -1041,8 +1041,24 @@ int launch_tn(kp1_mlp* m, GemmTN t, int n_o_tiles, int slab_cols, float* slab, i
 
 int launch_fused(const FusedArgs& fa, hipStream_t stream) {
   const size_t bytes = sizeof(float) * FU_LDS_FLOATS;
-  HIP_TRY(hipFuncSetAttribute((const void*)mlp_train_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  hipLaunchKernelGGL(mlp_train_tile_kernel, dim3((fa.n + FU_BM - 1) / FU_BM, 1, 2), dim3(FU_NTH), bytes, stream, fa);
+  HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  hipLaunchKernelGGL(mlp_tile_kernel<true>, dim3((fa.n + FU_BM - 1) / FU_BM, 1, 2), dim3(FU_NTH), bytes, stream, fa);
+  return KP1_OK;
+}
+
+int launch_fused_infer(const FusedArgs& fa, hipStream_t stream) {
+  const size_t bytes = sizeof(float) * FU_LDS_FLOATS;
+  HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  // the value net is skipped when no value is asked for (deterministic evaluators), the policy net when only values are
+  const bool want_pi = fa.mean || fa.action || fa.clipped || fa.log_prob;
+  if (!want_pi && !fa.value) return KP1_OK;
+  FusedArgs f = fa;
+  if (want_pi && fa.value) {
+    hipLaunchKernelGGL(mlp_tile_kernel<false>, dim3((fa.n + FU_BM - 1) / FU_BM, 1, 2), dim3(FU_NTH), bytes, stream, f);
+  } else {
+    f.net_base = want_pi ? 0 : 1;
+    hipLaunchKernelGGL(mlp_tile_kernel<false>, dim3((fa.n + FU_BM - 1) / FU_BM, 1, 1), dim3(FU_NTH), bytes, stream, f);
+  }
   return KP1_OK;
 }
 
@@ -1193,6 +1209,16 @@ int kp1_mlp_forward(kp1_mlp* m, const float* obs, int32_t obs_stride, int32_t n,
   if (obs_stride != IN && obs_stride != INP) return fail(KP1_ERR_INVALID, "obs_stride must be 56 or 64");
   int rc = mlp_check_device(m);
   if (rc != KP1_OK) return rc;
+  if (m->fused && m->Hp == FU_HP) {
+    FusedArgs fa{};
+    fa.obs = obs; fa.obs_stride = obs_stride; fa.Kreal = obs_stride >= INP ? INP : IN; fa.idx = nullptr; fa.n = n;
+    fa.k = m->k;
+    fa.noise = noise; fa.mean = mean; fa.value = value; fa.action = action; fa.clipped = clipped_action; fa.log_prob = log_prob;
+    rc = launch_fused_infer(fa, (hipStream_t)stream);
+    if (rc != KP1_OK) return rc;
+    HIP_TRY(hipGetLastError());
+    return KP1_OK;
+  }
   rc = launch_forward_layers(m, obs, obs_stride, nullptr, n, (hipStream_t)stream);
   if (rc != KP1_OK) return rc;
   HeadArgs a{};
@@ -1359,10 +1385,32 @@ int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32
         t.D = m->dz2; t.ldd = Hp; t.strideD = act_stride; t.X = m->h1; t.ldx = Hp; t.strideX = act_stride;
         t.Nload = Hp; t.n_i_tiles = Hp / 128;
         if (launch_tn(m, t, Hp / 128, Hp, m->slab, nullptr, stream) != KP1_OK) return KP1_ERR_NO_DEVICE;
-      } else {
+      } else if (which == 3) {
         g.A = obs; g.lda = obs_stride; g.strideA = 0; g.W = m->k.w1p; g.strideW = (int64_t)Hp * INP; g.bias = m->k.b1; g.strideBias = Hp;
         g.C = m->h1; g.K = INP; g.Kreal = obs_stride >= INP ? INP : IN;
         if (launch_nt<EPI_BIAS_TANH>(g, stream) != KP1_OK) return KP1_ERR_NO_DEVICE;
+      } else if (which == 4) {
+        // the fused tile kernel on this workspace: rows 0..n of obs, loss inputs = finite scratch values (layer-2 activations)
+        FusedArgs fa{};
+        fa.obs = obs; fa.obs_stride = obs_stride; fa.Kreal = obs_stride >= INP ? INP : IN; fa.idx = nullptr; fa.n = n;
+        fa.k = m->k;
+        fa.actions = m->h2; fa.old_logp = m->h2 + (int64_t)ACT * n; fa.adv = m->h2 + (int64_t)(ACT + 1) * n; fa.ret = m->h2 + (int64_t)(ACT + 2) * n;
+        fa.adv_mode = 3; fa.adv_mean = 0.f; fa.adv_inv_std = 1.f;
+        fa.clip_range = 0.2f; fa.vf_coef = 0.5f; fa.inv_count = 1.f / n;
+        fa.h1 = m->h1; fa.dz2 = m->dz2; fa.dz1 = m->dz1; fa.act_stride = act_stride; fa.xf = m->xf;
+        fa.bslab = m->bslab; fa.hpart = m->hpart; fa.hpart_stride = 10 * Hp + 32;
+        if (launch_fused(fa, stream) != KP1_OK) return KP1_ERR_NO_DEVICE;
+      } else {
+        TnFragArgs t{};
+        t.dz2 = m->dz2; t.h1 = m->h1; t.dz1 = m->dz1; t.act_stride = act_stride; t.xf = m->xf;
+        t.slab2 = m->slab; t.s2_net = (int64_t)Hp * Hp; t.s2_chunk = 2 * t.s2_net;
+        t.slab1 = m->slab1; t.s1_net = (int64_t)Hp * INP; t.s1_chunk = 2 * t.s1_net;
+        t.groups = (n + FU_BM - 1) / FU_BM * (FU_BM / 8);
+        t.cg2 = ((t.groups + 31) / 32 + 7) / 8 * 8;
+        t.cg1 = ((t.groups + 63) / 64 + 7) / 8 * 8;
+        t.n_chunks2 = (t.groups + t.cg2 - 1) / t.cg2;
+        t.n_chunks1 = (t.groups + t.cg1 - 1) / t.cg1;
+        if (launch_tn_frag(t, stream) != KP1_OK) return KP1_ERR_NO_DEVICE;
       }
     }
     HIP_TRY(hipEventRecord(e1, stream));
@@ -1376,11 +1424,23 @@ int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32
     rc = time_it(which);
     if (rc != KP1_OK) return rc;
   }
+  out_ms[4] = out_ms[5] = 0.f;
+  out_flops[4] = out_flops[5] = 0.0;
+  if (Hp == FU_HP) {  // the fused training path (it rewrites h1 / dz2 / dz1 in fragment-major order, so it runs last)
+    for (int which : {4, 5}) {
+      rc = time_it(which);
+      if (rc != KP1_OK) return rc;
+    }
+  }
   const double M = n, H = Hp;
   out_flops[0] = 2.0 * 2.0 * M * H * H;
   out_flops[1] = 2.0 * 2.0 * M * H * H;
   out_flops[2] = 2.0 * 2.0 * M * H * H;
   out_flops[3] = 2.0 * 2.0 * M * H * INP;
+  if (Hp == FU_HP) {
+    out_flops[4] = 2.0 * 2.0 * M * (H * (double)INP + 2.0 * H * H);  // layer 1 + layer 2 + activation backward (heads: < 3 % more)
+    out_flops[5] = 2.0 * 2.0 * M * (H * H + H * (double)INP);        // dW2 + dW1
+  }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return KP1_OK;

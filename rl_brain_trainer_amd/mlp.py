@@ -86,8 +86,9 @@ class MlpKernels:
 
     def time_kernels(self, obs: torch.Tensor, n: int, iters: int = 20) -> dict[str, dict[str, float]]:
         """HIP-event timings of the MFMA GEMM kernels at minibatch size n (bench.py roofline block)."""
-        ms = (C.c_float * 4)()
-        fl = (C.c_double * 4)()
+        ms = (C.c_float * 6)()
+        fl = (C.c_double * 6)()
         native.check(self.L.kp1_mlp_time_kernels(self._h, _p(obs), obs.shape[-1], n, iters, C.cast(ms, C.c_void_p), C.cast(fl, C.c_void_p), self._stream()))
-        names = ("gemm_nt_fwd_l2", "gemm_nt_bwd_dz1", "gemm_tn_dw2", "gemm_nt_fwd_l1")
-        return {nm: {"ms": float(ms[i]), "flops": float(fl[i]), "tflops": float(fl[i]) / (float(ms[i]) * 1e-3) / 1e12} for i, nm in enumerate(names)}
+        names = ("gemm_nt_fwd_l2", "gemm_nt_bwd_dz1", "gemm_tn_dw2", "gemm_nt_fwd_l1", "mlp_train_tile", "gemm_tn_frag")
+        return {nm: {"ms": float(ms[i]), "flops": float(fl[i]), "tflops": float(fl[i]) / (float(ms[i]) * 1e-3) / 1e12}
+                for i, nm in enumerate(names) if ms[i] > 0}

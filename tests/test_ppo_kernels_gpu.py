@@ -69,10 +69,12 @@ def test_fused_tile_kernel_matches_layerwise_kernels_and_is_reproducible():
     k.close()
 
 
-@pytest.mark.parametrize("n,stride", [(4096, 56), (4096, 64), (100, 56), (8192, 64), (12000, 64)])
-def test_mlp_forward_vs_torch(n, stride):
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("n,stride", [(4096, 56), (4096, 64), (100, 56), (8192, 64), (12000, 64), (1, 64)])
+def test_mlp_forward_vs_torch(n, stride, fused):
     pol = _policy()
     k = MlpKernels(256, DEV, max_batch=16384)
+    k.set_fused(fused)
     k.pack(pol.flat)
     g = torch.Generator(device=DEV).manual_seed(0)
     obs = torch.rand((n, stride), device=DEV, generator=g) * 2 - 1
@@ -93,6 +95,13 @@ def test_mlp_forward_vs_torch(n, stride):
     assert torch.allclose(clipped, ref_action.clamp(-1, 1), rtol=1e-4, atol=5e-5)
     ref_logp = P.gaussian_log_prob(ref_action, ref_mean, pol.views["log_std"])
     assert torch.allclose(logp, ref_logp, rtol=1e-4, atol=1e-4)
+    # single-output calls (the fused path launches only the net that is asked for)
+    value2 = torch.empty(n, device=DEV)
+    k.forward(obs, value=value2)
+    assert torch.equal(value2, value)
+    mean2 = torch.empty((n, 7), device=DEV)
+    k.forward(obs, mean=mean2)
+    assert torch.equal(mean2, mean)
     k.close()
 
 

@@ -5,7 +5,7 @@ at the phase boundaries), runs the layer-2 forward GEMM at the bench minibatch a
 the first workgroup's start: when workgroups start, how long the prologue, each pair of W stages and the epilogue take.
 
     python tools/nt_timeline.py [rows]            # layer-wise gemm_nt (the last NT launch of time_kernels = bwd dZ1)
-    python tools/nt_timeline.py [rows] fused      # mlp_train_tile_kernel (one loss_grad call)
+    python tools/nt_timeline.py [rows] fused      # mlp_tile_kernel<true> (one loss_grad call)
     python tools/nt_timeline.py [rows] tnfrag     # gemm_tn_frag_kernel (the launch after it in the same loss_grad call)
 """
 import ctypes as C
