@@ -1,0 +1,534 @@
+"""Random-start full-workspace coverage evaluation on the device engine.
+
+Mirror of the reference's
+
+  workspace/workspace_target_map.py:76-157        generate_workspace_target_map
+  workspace/workspace_start_state_map.py:62-134   generate_workspace_start_state_map
+  workspace/start_target_pair_sampler.py:31-115   classify_pair, build_pair_sampler_summary
+  workspace/adaptive_frontier_sampler.py:22-80    classify_bucket, update_bucket_priorities
+  eval/eval_full_workspace_coverage.py:58-308     _select_pairs, _run_pairs, _summarize, _bucket_metrics,
+                                                  evaluate_full_workspace_coverage
+
+with the same function names, argument meaning, seeds (seed+1 targets, seed+2 starts, seed+3 pairs, seed for the split
+selection, seed+4 home-stage eval) and row / summary keys.  The maps are host logic (a few thousand numpy Generator
+draws in the reference's order); forward kinematics of the sampled joint vectors runs batched on the GPU in fp64
+(``vec_env.fk_pose6``; tests inject the oracle's FK to check the maps without a GPU), and all episodes of a split run
+in lock step in ONE vectorised env (``evaluate.run_episodes``) instead of one ``ArmKinematicEnv`` per pair.
+"""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+from typing import Any, Callable, Sequence
+
+import numpy as np
+
+from . import config as kcfg
+
+FkFn = Callable[[np.ndarray], np.ndarray]  # q[n,7] float64 -> pose6[n,6] float64
+
+
+def _device_fk(device: int = 0) -> FkFn:
+    import torch
+
+    from .vec_env import fk_pose6
+
+    def fk(q: np.ndarray) -> np.ndarray:
+        if q.shape[0] == 0:
+            return np.zeros((0, 6))
+        return fk_pose6(torch.tensor(np.ascontiguousarray(q), dtype=torch.float64, device=torch.device("cuda", device))).cpu().numpy()
+
+    return fk
+
+
+# --------------------------------------------------------------------------------------------- joint helpers
+def _limits(env_cfg: kcfg.EnvConfig) -> tuple[np.ndarray, np.ndarray]:
+    c = env_cfg.c
+    return np.array(c.joints.lower[:], dtype=float), np.array(c.joints.upper[:], dtype=float)
+
+
+def joint_limit_margin(q: np.ndarray, lo: np.ndarray, hi: np.ndarray) -> np.ndarray:
+    """kinematics/joint_limits.py:166-174"""
+    span = np.maximum(hi - lo, 1e-9)
+    q = np.asarray(q, dtype=float)
+    return np.clip(2.0 * np.minimum((q - lo) / span, (hi - q) / span), 0.0, 1.0)
+
+
+def sample_joint_configuration(rng: np.random.Generator, lo: np.ndarray, hi: np.ndarray, margin_fraction: float = 0.1) -> np.ndarray:
+    """kinematics/joint_limits.py:138-150: one vector draw in [lo + m, hi - m], m = max(span * frac, 1e-6)"""
+    margin = np.maximum((hi - lo) * margin_fraction, 1e-6)
+    return rng.uniform(low=lo + margin, high=hi - margin, size=(lo.shape[0],)).astype(float)
+
+
+def sample_stage_joint_target(rng: np.random.Generator, base_q: Sequence[float], noise_q: Sequence[float], lo: np.ndarray, hi: np.ndarray) -> np.ndarray:
+    """envs/curriculum.py:90-101: the uniform draw happens only if some noise component is positive"""
+    base = np.asarray(base_q, dtype=float)
+    noise = np.asarray(noise_q, dtype=float)
+    if np.any(noise > 0.0):
+        base = base + rng.uniform(low=-noise, high=noise)
+    return np.clip(base, lo, hi)
+
+
+def _stage_arrays(env_cfg: kcfg.EnvConfig, stage_id: int) -> tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+    st = env_cfg.c.stages[stage_id]
+    return (np.array(st.start_q[:], dtype=float), np.array(st.start_noise[:], dtype=float), np.array(st.goal_q[:], dtype=float),
+            np.array(st.goal_noise[:], dtype=float))
+
+
+def _selected_stages(env_cfg: kcfg.EnvConfig, stage_indices: Sequence[int] | None) -> list[int]:
+    n = env_cfg.n_stages
+    sel = list(stage_indices) if stage_indices is not None else list(range(n))
+    return [int(np.clip(i, 0, n - 1)) for i in sel]
+
+
+# --------------------------------------------------------------------------------------------- target map
+def _bucketize(values: np.ndarray, lower: np.ndarray, upper: np.ndarray, bins: int) -> list[int]:
+    scaled = (np.asarray(values, dtype=float) - lower) / np.maximum(upper - lower, 1e-9)
+    return np.clip(np.floor(scaled * bins), 0, bins - 1).astype(int).tolist()
+
+
+def _difficulty(q: np.ndarray, pose6: np.ndarray, margin_min: float) -> float:
+    q_term = min(float(np.linalg.norm(q)) / 4.5, 1.0)
+    ori_term = min(float(np.linalg.norm(pose6[3:])) / np.pi, 1.0)
+    margin_term = 1.0 - float(np.clip(margin_min, 0.0, 1.0))
+    return float(0.45 * q_term + 0.35 * ori_term + 0.20 * margin_term)
+
+
+def generate_workspace_target_map(env_cfg: kcfg.EnvConfig, *, seed: int, stage_samples_per_stage: int, random_samples: int,
+                                  stage_indices: Sequence[int] | None = None, xyz_bins: int = 8, ori_bins: int = 6, q_l2_bins: int = 6,
+                                  fk: FkFn | None = None) -> tuple[list[dict[str, Any]], dict[str, Any]]:
+    fk = fk or _device_fk()
+    lo, hi = _limits(env_cfg)
+    rng = np.random.default_rng(seed)
+    selected = _selected_stages(env_cfg, stage_indices)
+    raw: list[tuple[np.ndarray, int | None, str]] = []
+    for stage_id in selected:
+        _, _, goal_q, goal_noise = _stage_arrays(env_cfg, stage_id)
+        for _ in range(max(stage_samples_per_stage, 0)):
+            raw.append((sample_stage_joint_target(rng, goal_q, goal_noise, lo, hi), stage_id, "stage_distribution"))
+    for _ in range(max(random_samples, 0)):
+        raw.append((sample_joint_configuration(rng, lo, hi, margin_fraction=0.08), None, "random_valid_q"))
+
+    q_all = np.vstack([r[0] for r in raw]) if raw else np.zeros((0, kcfg.NJ))
+    poses = fk(q_all)
+    if len(poses):
+        xyz_lower = poses[:, :3].min(axis=0) - 1e-6
+        xyz_upper = poses[:, :3].max(axis=0) + 1e-6
+    else:
+        xyz_lower, xyz_upper = np.asarray([-1.0, -1.0, 0.0]), np.asarray([1.0, 1.0, 2.0])
+
+    samples: list[dict[str, Any]] = []
+    for idx, (q, stage_id, source_type) in enumerate(raw):
+        pose6 = poses[idx]
+        margin_min = float(np.min(joint_limit_margin(q, lo, hi)))
+        xyz_bucket = _bucketize(pose6[:3], xyz_lower, xyz_upper, xyz_bins)
+        ori_bucket = int(np.clip(np.floor(float(np.linalg.norm(pose6[3:])) / np.pi * ori_bins), 0, ori_bins - 1))
+        q_bucket = int(np.clip(np.floor(float(np.linalg.norm(q)) / 4.5 * q_l2_bins), 0, q_l2_bins - 1))
+        samples.append({
+            "target_id": f"target_{idx:06d}", "q_target": q.astype(float).tolist(), "ee_target_position": pose6[:3].astype(float).tolist(),
+            "ee_target_orientation": pose6[3:].astype(float).tolist(), "stage_id": stage_id, "source_type": source_type,
+            "bucket_id": f"x{xyz_bucket[0]}_y{xyz_bucket[1]}_z{xyz_bucket[2]}_o{ori_bucket}_q{q_bucket}", "xyz_bucket": xyz_bucket,
+            "orientation_bucket": ori_bucket, "joint_l2_bucket": q_bucket, "joint_limit_margin_min": margin_min,
+            "reachability_flag": bool(margin_min > 0.0), "difficulty_score": _difficulty(q, pose6, margin_min),
+            "previous_eval_success_rate": None, "previous_failure_reason_counts": None,
+        })
+
+    q_stack = np.vstack([np.asarray(s["q_target"], dtype=float) for s in samples]) if samples else np.zeros((0, kcfg.NJ))
+    pos_stack = np.vstack([np.asarray(s["ee_target_position"], dtype=float) for s in samples]) if samples else np.zeros((0, 3))
+    summary = {
+        "seed": int(seed), "total_target_count": len(samples), "valid_target_count": sum(1 for s in samples if s["reachability_flag"]),
+        "rejected_target_count": 0, "stage_indices": selected,
+        "xyz_span": (pos_stack.max(axis=0) - pos_stack.min(axis=0)).tolist() if len(pos_stack) else [0.0, 0.0, 0.0],
+        "xyz_min": pos_stack.min(axis=0).tolist() if len(pos_stack) else [0.0, 0.0, 0.0],
+        "xyz_max": pos_stack.max(axis=0).tolist() if len(pos_stack) else [0.0, 0.0, 0.0],
+        "q_l2_range": [float(np.min(np.linalg.norm(q_stack, axis=1))), float(np.max(np.linalg.norm(q_stack, axis=1)))] if len(q_stack) else [0.0, 0.0],
+        "joint_limit_margin_min": float(min((s["joint_limit_margin_min"] for s in samples), default=0.0)),
+        "joint_limit_margin_mean": float(np.mean([s["joint_limit_margin_min"] for s in samples])) if samples else 0.0,
+        "bucket_count": len({s["bucket_id"] for s in samples}),
+        "stage_is_workspace_note": "Stage IDs are difficulty shells, not the full continuous workspace.",
+    }
+    return samples, summary
+
+
+# --------------------------------------------------------------------------------------------- start-state map
+def _start_bucket_id(pose6: np.ndarray, q: np.ndarray, margin_min: float) -> str:
+    x = int(np.clip(np.floor((pose6[0] + 1.0) / 2.0 * 8), 0, 7))
+    y = int(np.clip(np.floor((pose6[1] + 1.0) / 2.0 * 8), 0, 7))
+    z = int(np.clip(np.floor((pose6[2]) / 2.0 * 6), 0, 5))
+    q_bucket = int(np.clip(np.floor(np.linalg.norm(q) / 4.5 * 6), 0, 5))
+    m_bucket = int(np.clip(np.floor(margin_min * 5), 0, 4))
+    return f"x{x}_y{y}_z{z}_q{q_bucket}_m{m_bucket}"
+
+
+def _stability_score(margin_min: float, dq: np.ndarray, prev_action: np.ndarray) -> float:
+    motion = min(float(np.linalg.norm(dq)) + float(np.linalg.norm(prev_action)), 1.0)
+    return float(0.7 * np.clip(margin_min, 0.0, 1.0) + 0.3 * (1.0 - motion))
+
+
+def generate_workspace_start_state_map(env_cfg: kcfg.EnvConfig, *, seed: int, stage_samples_per_stage: int, random_samples: int,
+                                       stage_indices: Sequence[int] | None = None, dq_noise: float = 0.001, prev_action_noise: float = 0.03,
+                                       fk: FkFn | None = None) -> tuple[list[dict[str, Any]], dict[str, Any]]:
+    fk = fk or _device_fk()
+    lo, hi = _limits(env_cfg)
+    rng = np.random.default_rng(seed)
+    selected = _selected_stages(env_cfg, stage_indices)
+    raw: list[tuple[np.ndarray, str, int | None, str | None]] = [(np.zeros(kcfg.NJ, dtype=float), "home", 0, None)]
+    for stage_id in selected:
+        start_q, start_noise, goal_q, goal_noise = _stage_arrays(env_cfg, stage_id)
+        for sample_idx in range(max(stage_samples_per_stage, 0)):
+            if rng.random() < 0.65:
+                q = sample_stage_joint_target(rng, goal_q, goal_noise, lo, hi)
+                source = "successful_rollout"
+            else:
+                q = sample_stage_joint_target(rng, start_q, start_noise, lo, hi)
+                source = "near_target" if stage_id >= 6 else "successful_rollout"
+            raw.append((q, source, stage_id, f"stage{stage_id:02d}_synthetic_{sample_idx:04d}"))
+    for sample_idx in range(max(random_samples, 0)):
+        raw.append((sample_joint_configuration(rng, lo, hi, margin_fraction=0.10), "random_valid_q", None, f"random_{sample_idx:04d}"))
+
+    # the dq / prev_action draws follow ALL q draws, two vector draws per sample in sample order (home included, then zeroed)
+    motion = []
+    for _q, source, _s, _r in raw:
+        dq = rng.uniform(-dq_noise, dq_noise, size=kcfg.NJ)
+        prev_action = rng.uniform(-prev_action_noise, prev_action_noise, size=kcfg.NJ)
+        if source == "home":
+            dq = np.zeros(kcfg.NJ, dtype=float)
+            prev_action = np.zeros(kcfg.NJ, dtype=float)
+        motion.append((dq, prev_action))
+    poses = fk(np.vstack([r[0] for r in raw]))
+
+    samples: list[dict[str, Any]] = []
+    for idx, (q, source, stage_id, rollout_id) in enumerate(raw):
+        dq, prev_action = motion[idx]
+        pose6 = poses[idx]
+        margin_min = float(np.min(joint_limit_margin(q, lo, hi)))
+        samples.append({
+            "start_id": f"start_{idx:06d}", "q_start": q.astype(float).tolist(), "dq_start": dq.astype(float).tolist(),
+            "prev_action": prev_action.astype(float).tolist(), "ee_position": pose6[:3].astype(float).tolist(),
+            "ee_orientation": pose6[3:].astype(float).tolist(), "source_type": source, "source_stage": stage_id, "source_rollout_id": rollout_id,
+            "stability_score": _stability_score(margin_min, dq, prev_action), "joint_limit_margin_min": margin_min,
+            "bucket_id": _start_bucket_id(pose6, q, margin_min),
+        })
+    source_counts: dict[str, int] = {}
+    for s in samples:
+        source_counts[s["source_type"]] = source_counts.get(s["source_type"], 0) + 1
+    pos_stack = np.vstack([np.asarray(s["ee_position"], dtype=float) for s in samples])
+    summary = {
+        "seed": int(seed), "total_start_count": len(samples), "source_counts": source_counts, "bucket_count": len({s["bucket_id"] for s in samples}),
+        "xyz_span": (pos_stack.max(axis=0) - pos_stack.min(axis=0)).tolist(),
+        "joint_limit_margin_min": float(min((s["joint_limit_margin_min"] for s in samples), default=0.0)),
+        "joint_limit_margin_mean": float(np.mean([s["joint_limit_margin_min"] for s in samples])),
+        "random_start_note": "Start states intentionally include non-home q states; this is the core distinction from prior home-start stage sweeps.",
+    }
+    return samples, summary
+
+
+# --------------------------------------------------------------------------------------------- pairs
+LOCAL_Q_L2, MEDIUM_Q_L2, FRONTIER_SUCCESS_LOW, FRONTIER_SUCCESS_HIGH = 0.28, 0.70, 0.35, 0.80
+
+
+def classify_pair(*, start: dict[str, Any], target: dict[str, Any], q_l2: float) -> str:
+    target_success = target.get("previous_eval_success_rate")
+    if start.get("source_type") in {"home", "successful_rollout"} and target.get("stage_id") is not None and int(target["stage_id"]) <= 7:
+        return "retention"
+    if q_l2 <= LOCAL_Q_L2:
+        return "local"
+    if target_success is not None:
+        success = float(target_success)
+        if FRONTIER_SUCCESS_LOW <= success <= FRONTIER_SUCCESS_HIGH:
+            return "frontier"
+        if success < FRONTIER_SUCCESS_LOW:
+            return "stress"
+    if q_l2 <= MEDIUM_Q_L2:
+        return "medium"
+    return "frontier" if int(target.get("stage_id") or 0) <= 10 else "stress"
+
+
+def build_pair_sampler_summary(*, starts: list[dict[str, Any]], targets: list[dict[str, Any]], seed: int, pair_count: int
+                               ) -> tuple[list[dict[str, Any]], dict[str, Any]]:
+    rng = np.random.default_rng(seed)
+    if not starts or not targets:
+        return [], {"pair_count": 0, "reason": "empty start or target map"}
+    pairs: list[dict[str, Any]] = []
+    for idx in range(max(pair_count, 0)):
+        start = starts[int(rng.integers(0, len(starts)))]
+        target = targets[int(rng.integers(0, len(targets)))]
+        q_l2 = float(np.linalg.norm(np.asarray(target["q_target"], dtype=float) - np.asarray(start["q_start"], dtype=float)))
+        start_pos, target_pos = np.asarray(start["ee_position"], dtype=float), np.asarray(target["ee_target_position"], dtype=float)
+        pairs.append({
+            "pair_id": f"pair_{idx:06d}", "start_id": start["start_id"], "target_id": target["target_id"],
+            "start_source_type": start.get("source_type"), "target_source_type": target.get("source_type"), "target_stage_id": target.get("stage_id"),
+            "start_bucket_id": start.get("bucket_id"), "target_bucket_id": target.get("bucket_id"), "joint_distance_l2": q_l2,
+            "ee_position_distance": float(np.linalg.norm(target_pos - start_pos)),
+            "orientation_distance": float(np.linalg.norm(np.asarray(target["ee_target_orientation"], dtype=float) - np.asarray(start["ee_orientation"], dtype=float))),
+            "z_displacement": float(abs(target_pos[2] - start_pos[2])),
+            "start_joint_limit_margin": float(start.get("joint_limit_margin_min", 0.0)),
+            "target_joint_limit_margin": float(target.get("joint_limit_margin_min", 0.0)),
+            "difficulty_class": classify_pair(start=start, target=target, q_l2=q_l2),
+        })
+    class_counts: dict[str, int] = {}
+    for p in pairs:
+        class_counts[str(p["difficulty_class"])] = class_counts.get(str(p["difficulty_class"]), 0) + 1
+    summary = {
+        "seed": int(seed), "pair_count": len(pairs), "start_count": len(starts), "target_count": len(targets), "difficulty_class_counts": class_counts,
+        "mean_joint_distance_l2": float(np.mean([p["joint_distance_l2"] for p in pairs])) if pairs else 0.0,
+        "mean_ee_position_distance": float(np.mean([p["ee_position_distance"] for p in pairs])) if pairs else 0.0,
+        "max_joint_distance_l2": float(max((p["joint_distance_l2"] for p in pairs), default=0.0)),
+        "pair_curriculum_note": "Pairs are classified for layered curriculum; full-random stress pairs should remain a minority during training.",
+    }
+    return pairs, summary
+
+
+def select_pairs(pairs: list[dict[str, Any]], *, mode: str, limit: int, rng: np.random.Generator) -> list[dict[str, Any]]:
+    """eval_full_workspace_coverage.py:58-72"""
+    if mode == "known":
+        pool = [p for p in pairs if int(p.get("target_stage_id") or 0) <= 8 and p.get("difficulty_class") in {"retention", "local", "medium"}]
+    elif mode == "frontier":
+        pool = [p for p in pairs if 8 <= int(p.get("target_stage_id") or 0) <= 11 and p.get("difficulty_class") in {"medium", "frontier", "stress"}]
+    elif mode == "stress":
+        pool = pairs
+    else:
+        raise ValueError(f"Unknown pair eval mode: {mode}")
+    if not pool:
+        pool = pairs
+    if len(pool) <= limit:
+        return list(pool)
+    indices = rng.choice(len(pool), size=limit, replace=False)
+    return [pool[int(i)] for i in indices]
+
+
+# --------------------------------------------------------------------------------------------- bucket priorities
+def classify_bucket(*, success_rate: float, mean_min_error: float, mean_final_error: float, previous_success_rate: float | None = None) -> str:
+    if previous_success_rate is not None and previous_success_rate >= 0.75 and success_rate < previous_success_rate - 0.20:
+        return "forgetting_risk"
+    if success_rate >= 0.85:
+        return "mastered"
+    if 0.35 <= success_rate < 0.85:
+        return "frontier"
+    if success_rate < 0.20 and mean_min_error > 0.025:
+        return "too_hard"
+    if mean_min_error <= 0.012 and mean_final_error > mean_min_error + 0.006:
+        return "hard_but_promising"
+    return "stress"
+
+
+def priority_for_category(category: str) -> float:
+    return {"mastered": 0.15, "frontier": 1.00, "hard_but_promising": 0.95, "forgetting_risk": 1.10, "stress": 0.25, "too_hard": 0.05}.get(category, 0.20)
+
+
+def update_bucket_priorities(bucket_metrics: dict[str, dict[str, Any]]) -> list[dict[str, Any]]:
+    out: list[dict[str, Any]] = []
+    for bucket_id, m in bucket_metrics.items():
+        success_rate = float(m.get("success_rate", 0.0))
+        mean_min_error = float(m.get("mean_min_position_error", m.get("mean_min_error", 999.0)))
+        mean_final_error = float(m.get("mean_final_position_error", m.get("mean_final_error", 999.0)))
+        previous = m.get("previous_success_rate")
+        previous_success_rate = float(previous) if previous is not None else None
+        category = classify_bucket(success_rate=success_rate, mean_min_error=mean_min_error, mean_final_error=mean_final_error,
+                                   previous_success_rate=previous_success_rate)
+        failure_count = int(m.get("failure_count", 0))
+        out.append({"bucket_id": bucket_id, "success_rate": success_rate, "mean_min_error": mean_min_error, "mean_final_error": mean_final_error,
+                    "previous_success_rate": previous_success_rate, "failure_count": failure_count, "category": category,
+                    "sampling_priority": float(priority_for_category(category) * (1.0 + min(failure_count, 20) / 40.0))})
+    return sorted(out, key=lambda item: item["sampling_priority"], reverse=True)
+
+
+# --------------------------------------------------------------------------------------------- summaries
+def _mean(values: Sequence[float | bool]) -> float:
+    return float(np.mean(values)) if len(values) else 0.0
+
+
+def summarize(rows: list[dict[str, Any]]) -> dict[str, Any]:
+    reasons: dict[str, int] = {}
+    by_source: dict[str, list[dict[str, Any]]] = {}
+    for row in rows:
+        reasons[row["failure_reason"]] = reasons.get(row["failure_reason"], 0) + 1
+        by_source.setdefault(str(row.get("start_source_type", "unknown")), []).append(row)
+    return {
+        "episode_count": len(rows), "success_rate": _mean([r["success"] for r in rows]), "ready_rate": _mean([r["finisher_ready_hit"] for r in rows]),
+        "dwell_success_rate": _mean([r["finisher_ready_dwell"] for r in rows]),
+        "mean_final_position_error": _mean([r["final_position_error"] for r in rows]),
+        "mean_final_orientation_error": _mean([r["final_orientation_error"] for r in rows]),
+        "mean_final_action_magnitude": _mean([r["final_action_magnitude"] for r in rows]), "mean_final_dq_norm": _mean([r["final_dq_norm"] for r in rows]),
+        "average_start_target_joint_distance": _mean([r["joint_distance_l2"] for r in rows]),
+        "average_start_target_ee_distance": _mean([r["ee_position_distance"] for r in rows]),
+        "max_successful_joint_l2": max((r["joint_distance_l2"] for r in rows if r["success"]), default=0.0), "failure_reason_counts": reasons,
+        "success_by_start_source": {src: {"episode_count": len(items), "success_rate": _mean([i["success"] for i in items])} for src, items in by_source.items()},
+    }
+
+
+def bucket_metrics(rows: list[dict[str, Any]]) -> dict[str, dict[str, Any]]:
+    grouped: dict[str, list[dict[str, Any]]] = {}
+    for row in rows:
+        grouped.setdefault(str(row["target_bucket_id"]), []).append(row)
+    return {b: {"episode_count": len(items), "success_rate": _mean([i["success"] for i in items]), "failure_count": sum(1 for i in items if not i["success"]),
+                "mean_final_position_error": _mean([i["final_position_error"] for i in items]),
+                "mean_min_position_error": _mean([i["min_position_error"] for i in items])} for b, items in grouped.items()}
+
+
+def failure_reason(approach: dict[str, float], r, success: bool, dwell: bool) -> str:
+    """eval_full_workspace_coverage.py:43-55 (r = the approach env's reward config)"""
+    if success:
+        return "success"
+    if approach["final_position_error"] > r.finisher_ready_pos_threshold_m:
+        return "position"
+    if approach["final_orientation_error"] > r.finisher_ready_ori_threshold_rad:
+        return "orientation"
+    if approach["final_action_magnitude"] > r.finisher_ready_action_threshold:
+        return "motion_action"
+    if approach["final_dq_norm"] > r.finisher_ready_dq_threshold:
+        return "motion_dq"
+    if not dwell:
+        return "dwell"
+    return "timeout_or_regression"
+
+
+# --------------------------------------------------------------------------------------------- batched pair runner
+def run_pairs(*, pairs: list[dict[str, Any]], starts_by_id: dict[str, dict[str, Any]], targets_by_id: dict[str, dict[str, Any]], approach_policy,
+              approach_cfg: kcfg.EnvConfig, finisher_policy=None, finisher_cfg: kcfg.EnvConfig | None = None, handoff_confirm_steps: int = 2,
+              device: int = 0, obs_stride: int = 56, seed: int = 0) -> list[dict[str, Any]]:
+    """_run_pairs: every pair is one env of a vectorised Approach run (explicit initial state and goal), then the handed-off
+    ones continue in a vectorised Finisher run."""
+    import torch
+
+    from . import evaluate as ev
+    from .vec_env import ArmKinematicVecEnv
+
+    E = len(pairs)
+    if E == 0:
+        return []
+    nj = kcfg.NJ
+    starts = [starts_by_id[p["start_id"]] for p in pairs]
+    targets = [targets_by_id[p["target_id"]] for p in pairs]
+    opts = {
+        "initial_q": np.array([s["q_start"] for s in starts], dtype=float),
+        "initial_dq": np.array([s.get("dq_start", [0.0] * nj) for s in starts], dtype=float),
+        "initial_prev_action": np.array([s.get("prev_action", [0.0] * nj) for s in starts], dtype=float),
+        "goal_q": np.array([t["q_target"] for t in targets], dtype=float),
+        "goal_pose6": np.array([[*t["ee_target_position"], *t["ee_target_orientation"]] for t in targets], dtype=float),
+        "policy_mode": "approach",
+    }
+    r = approach_cfg.c.reward
+    env = ArmKinematicVecEnv(approach_cfg, E, device=device, seed=seed)
+    if obs_stride != 56:
+        env.set_obs_stride(obs_stride)
+    a_res, hand = ev.run_episodes(env, approach_policy, opts, ready_cfg=r, handoff_confirm_steps=handoff_confirm_steps)
+    env.close()
+    final_ready = ev.finisher_ready(a_res["final_position_error"], a_res["final_orientation_error"], a_res["final_action_magnitude"], a_res["final_dq_norm"], r)
+    has_hand = final_ready | hand["valid"]
+    src = {}
+    for k in ("state_q", "state_dq", "state_prev_action", "state_goal_q", "state_goal_pose6"):
+        src[k] = torch.where(final_ready[:, None], a_res[k], hand.get(k, torch.zeros_like(a_res[k])))
+    final = {k: a_res[k].clone() for k in ("final_position_error", "final_orientation_error", "final_action_magnitude", "final_dq_norm")}
+    success = a_res["success"].clone()
+    if finisher_policy is not None and finisher_cfg is not None and bool(has_hand.any()):
+        fenv = ArmKinematicVecEnv(finisher_cfg, E, device=device, seed=seed)
+        if obs_stride != 56:
+            fenv.set_obs_stride(obs_stride)
+        safe = {k: torch.where(has_hand[:, None], v, a_res[k]) for k, v in src.items()}
+        f_res, _ = ev.run_episodes(fenv, finisher_policy, ev._handoff_options(safe, "dock"), active=has_hand)
+        fenv.close()
+        for k in final:
+            final[k] = torch.where(has_hand, f_res[k], final[k])
+        success = torch.where(has_hand, f_res["success"], success)
+    ready_hit = (a_res["ready_hit"] | final_ready).cpu().numpy()
+    ready_dwell = ((a_res["max_ready_streak"] >= handoff_confirm_steps) | final_ready).cpu().numpy()
+    coarse_dwell = (a_res["max_ready_streak"] >= handoff_confirm_steps).cpu().numpy()
+    A = {k: v.cpu().numpy() for k, v in a_res.items() if v.ndim == 1}
+    F = {k: v.cpu().numpy() for k, v in final.items()}
+    succ = success.cpu().numpy()
+    rows = []
+    for idx, pair in enumerate(pairs):
+        approach = {k: float(A[k][idx]) for k in ("final_position_error", "final_orientation_error", "final_action_magnitude", "final_dq_norm")}
+        rows.append({
+            "episode_id": idx, "pair_id": pair["pair_id"], "start_id": pair["start_id"], "target_id": pair["target_id"],
+            "start_source_type": pair.get("start_source_type"), "target_stage_id": pair.get("target_stage_id"), "target_bucket_id": pair.get("target_bucket_id"),
+            "difficulty_class": pair.get("difficulty_class"), "joint_distance_l2": float(pair.get("joint_distance_l2", 0.0)),
+            "ee_position_distance": float(pair.get("ee_position_distance", 0.0)), "success": bool(succ[idx]),
+            "finisher_ready_hit": bool(ready_hit[idx]), "finisher_ready_dwell": bool(ready_dwell[idx]),
+            "failure_reason": failure_reason(approach, r, bool(succ[idx]), bool(coarse_dwell[idx])),
+            "final_position_error": float(F["final_position_error"][idx]), "final_orientation_error": float(F["final_orientation_error"][idx]),
+            "approach_final_position_error": approach["final_position_error"], "approach_final_orientation_error": approach["final_orientation_error"],
+            "min_position_error": float(A["min_position_error"][idx]), "min_orientation_error": float(A["min_orientation_error"][idx]),
+            "final_action_magnitude": float(F["final_action_magnitude"][idx]), "final_dq_norm": float(F["final_dq_norm"][idx]),
+        })
+    return rows
+
+
+def _write_json(path: Path, payload: Any) -> None:
+    path.parent.mkdir(parents=True, exist_ok=True)
+    path.write_text(json.dumps(payload, indent=2))
+
+
+def _write_jsonl(path: Path, rows: list[dict[str, Any]]) -> None:
+    path.parent.mkdir(parents=True, exist_ok=True)
+    path.write_text("\n".join(json.dumps(r) for r in rows) + ("\n" if rows else ""))
+
+
+def evaluate_full_workspace_coverage(*, approach_policy, approach_cfg: kcfg.EnvConfig, artifact_root: str | Path | None = None, finisher_policy=None,
+                                     finisher_cfg: kcfg.EnvConfig | None = None, seed: int = 940001, episodes_per_split: int = 96,
+                                     stage_samples_per_stage: int = 96, random_target_samples: int = 384, random_start_samples: int = 384,
+                                     pair_count: int = 2048, handoff_confirm_steps: int = 2, include_home_stage_eval: bool = True, device: int = 0,
+                                     obs_stride: int = 56) -> dict[str, Any]:
+    """evaluate_full_workspace_coverage with policies passed as callables (checkpoint loading is the caller's); same artefact
+    files under ``artifact_root`` (maps/, *_random_start_eval_summary.json, workspace_bucket_metrics.json,
+    full_workspace_coverage_summary.json, workspace_failure_report.json, home_start_stage_eval/)."""
+    from . import evaluate as ev
+
+    rng = np.random.default_rng(seed)
+    root = Path(artifact_root) if artifact_root is not None else None
+    fk = _device_fk(device)
+    target_samples, target_summary = generate_workspace_target_map(approach_cfg, seed=seed + 1, stage_samples_per_stage=stage_samples_per_stage,
+                                                                   random_samples=random_target_samples, fk=fk)
+    start_samples, start_summary = generate_workspace_start_state_map(approach_cfg, seed=seed + 2, stage_samples_per_stage=max(stage_samples_per_stage // 2, 1),
+                                                                      random_samples=random_start_samples, fk=fk)
+    pairs, pair_summary = build_pair_sampler_summary(starts=start_samples, targets=target_samples, seed=seed + 3, pair_count=pair_count)
+    if root is not None:
+        _write_jsonl(root / "maps" / "target_map.jsonl", target_samples)
+        _write_json(root / "maps" / "target_map_summary.json", target_summary)
+        _write_jsonl(root / "maps" / "start_state_map.jsonl", start_samples)
+        _write_json(root / "maps" / "start_state_map_summary.json", start_summary)
+        _write_jsonl(root / "maps" / "start_target_pairs.jsonl", pairs)
+        _write_json(root / "maps" / "pair_sampler_summary.json", pair_summary)
+    starts_by_id = {row["start_id"]: row for row in start_samples}
+    targets_by_id = {row["target_id"]: row for row in target_samples}
+
+    split_rows: dict[str, list[dict[str, Any]]] = {}
+    for split in ("known", "frontier", "stress"):
+        selected = select_pairs(pairs, mode=split, limit=episodes_per_split, rng=rng)
+        rows = run_pairs(pairs=selected, starts_by_id=starts_by_id, targets_by_id=targets_by_id, approach_policy=approach_policy, approach_cfg=approach_cfg,
+                         finisher_policy=finisher_policy, finisher_cfg=finisher_cfg, handoff_confirm_steps=handoff_confirm_steps, device=device,
+                         obs_stride=obs_stride, seed=seed)
+        split_rows[split] = rows
+        if root is not None:
+            _write_json(root / f"{split}_random_start_eval_summary.json", {"summary": summarize(rows), "episode_rows": rows})
+
+    all_rows = [row for rows in split_rows.values() for row in rows]
+    bm = bucket_metrics(all_rows)
+    priorities = update_bucket_priorities(bm)
+    stable = sum(1 for d in bm.values() if float(d["success_rate"]) >= 0.85)
+    partial = sum(1 for d in bm.values() if 0.35 <= float(d["success_rate"]) < 0.85)
+    stress = sum(1 for d in bm.values() if float(d["success_rate"]) < 0.35)
+    coverage = {
+        "target_map_summary": target_summary, "start_state_map_summary": start_summary, "pair_sampler_summary": pair_summary,
+        "random_start_known_workspace": summarize(split_rows["known"]), "random_start_frontier": summarize(split_rows["frontier"]),
+        "full_reachable_stress": summarize(split_rows["stress"]),
+        "covered_bucket_fraction": float((stable + partial) / max(len(bm), 1)), "stable_bucket_fraction": float(stable / max(len(bm), 1)),
+        "partial_bucket_fraction": float(partial / max(len(bm), 1)), "stress_bucket_fraction": float(stress / max(len(bm), 1)),
+        "covered_bucket_count": int(stable + partial), "total_eval_bucket_count": len(bm), "top_sampling_priorities": priorities[:30],
+    }
+    if root is not None:
+        _write_json(root / "workspace_bucket_metrics.json", bm)
+        _write_json(root / "workspace_failure_report.json", {
+            split: {"failure_reason_counts": summarize(rows)["failure_reason_counts"],
+                    "worst_rows": sorted(rows, key=lambda row: row["final_position_error"] + 0.02 * row["final_orientation_error"], reverse=True)[:20]}
+            for split, rows in split_rows.items()})
+    if include_home_stage_eval:
+        home = ev.evaluate_workspace_expansion(approach_policy=approach_policy, finisher_policy=finisher_policy, approach_cfg=approach_cfg,
+                                               finisher_cfg=finisher_cfg, episodes=max(8, min(episodes_per_split // 4, 32)), seed=seed + 4,
+                                               stage_indices=list(range(approach_cfg.n_stages)), handoff_confirm_steps=handoff_confirm_steps,
+                                               artifact_root=(root / "home_start_stage_eval") if root is not None else None, device=device, obs_stride=obs_stride)
+        coverage["home_start_stage_metrics"] = home["stage_metrics"]
+    if root is not None:
+        _write_json(root / "full_workspace_coverage_summary.json", coverage)
+    return coverage

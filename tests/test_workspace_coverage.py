@@ -1,0 +1,144 @@
+"""Random-start workspace coverage against the reference's outputs (tests/golden/coverage_maps.json,
+written by tests/golden/make_golden_coverage.py).
+
+CPU tests inject the oracle's FK (the product path uses the batched device FK and has no CPU fallback); the GPU tests run
+the maps with the device FK and the whole evaluator end to end."""
+from __future__ import annotations
+
+import json
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden_config
+from oracle import oracle as orc
+from rl_brain_trainer_amd import workspace_coverage as wc
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return json.loads((GOLDEN / "coverage_maps.json").read_text())
+
+
+def _same(a, b, tol=1e-12):
+    if isinstance(b, dict):
+        assert isinstance(a, dict) and set(a) == set(b), (sorted(a), sorted(b))
+        for k in b:
+            _same(a[k], b[k], tol)
+    elif isinstance(b, (list, tuple)):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            _same(x, y, tol)
+    elif isinstance(b, float) and not isinstance(b, bool):
+        assert abs(float(a) - b) <= tol * max(1.0, abs(b)), (a, b)
+    else:
+        assert a == b, (a, b)
+
+
+def _maps(gold, fk):
+    cfg = load_golden_config(gold["config"])
+    sz, seed = gold["sizes"], gold["seed"]
+    targets, tsum = wc.generate_workspace_target_map(cfg, seed=seed + 1, stage_samples_per_stage=sz["target_stage_samples"],
+                                                     random_samples=sz["target_random"], fk=fk)
+    starts, ssum = wc.generate_workspace_start_state_map(cfg, seed=seed + 2, stage_samples_per_stage=sz["start_stage_samples"],
+                                                         random_samples=sz["start_random"], fk=fk)
+    return targets, tsum, starts, ssum
+
+
+def _check_maps(gold, fk):
+    targets, tsum, starts, ssum = _maps(gold, fk)
+    _same(targets, gold["targets"])
+    _same(tsum, gold["target_summary"])
+    _same(starts, gold["starts"])
+    _same(ssum, gold["start_summary"])
+    pairs, psum = wc.build_pair_sampler_summary(starts=starts, targets=targets, seed=gold["seed"] + 3, pair_count=gold["sizes"]["pair_count"])
+    _same(pairs, gold["pairs"])
+    _same(psum, gold["pair_summary"])
+    rng = np.random.default_rng(gold["seed"])
+    for mode in ("known", "frontier", "stress"):
+        sel = wc.select_pairs(pairs, mode=mode, limit=gold["sizes"]["limit"], rng=rng)
+        assert [p["pair_id"] for p in sel] == gold["selected"][mode]
+
+
+def test_maps_pairs_and_split_selection_match_reference_with_oracle_fk(gold):
+    _check_maps(gold, orc.fk_pose6)
+
+
+def test_classify_pair_cases(gold):
+    for c in gold["classify_cases"]:
+        assert wc.classify_pair(start=c["start"], target=c["target"], q_l2=c["q_l2"]) == c["class"], c
+
+
+def test_summaries_bucket_metrics_and_priorities(gold):
+    rows = gold["rows"]
+    _same(wc.summarize(rows), gold["summary"])
+    bm = wc.bucket_metrics(rows)
+    _same(bm, gold["bucket_metrics"])
+    _same(wc.update_bucket_priorities(bm), gold["priorities"])
+    _same(wc.update_bucket_priorities(gold["bucket_metrics_prev"]), gold["priorities_prev"])
+    with pytest.raises(ValueError):
+        wc.select_pairs([], mode="nope", limit=1, rng=np.random.default_rng(0))
+
+
+@pytest.mark.gpu
+def test_maps_with_device_fk_match_reference(gold):
+    _check_maps(gold, None)
+
+
+@pytest.mark.gpu
+def test_coverage_evaluator_end_to_end_matches_serial_oracle(tmp_path, gold):
+    """A servo policy through evaluate_full_workspace_coverage: every row of the batched Approach->Finisher run equals the
+    reference's serial per-pair loop restated on the CPU oracle (success flags, ready flags, final errors)."""
+    import torch
+
+    from rl_brain_trainer_amd import evaluate as ev
+    from rl_brain_trainer_amd.vec_env import ArmKinematicVecEnv  # noqa: F401
+    from test_eval_checkpoint_gpu import _serial_oracle_episode
+
+    acfg = load_golden_config(gold["config"])
+    fcfg = load_golden_config("dock_workspace_handoff_noop_ft_12env_raw")
+    gain = 0.9
+    holder: dict = {}
+
+    class Servo:
+        """model.predict stand-in that reads the vectorised env the evaluator is currently stepping"""
+        def __call__(self, obs):
+            env = holder["env"]
+            dl = torch.tensor(env.config.c.joints.delta_limit[:], device="cuda", dtype=torch.float64)
+            scale = env.config.c.env.dock_action_delta_scale or env.config.c.env.action_delta_scale
+            info = env.info()
+            a = gain * (info["goal_q"].double().t() - info["q"].double().t()) / (dl * scale)
+            return a.clamp(-1, 1).to(env.dtype)
+
+    # run_episodes creates the envs internally; capture them through a thin wrapper around reset
+    orig_run = ev.run_episodes
+
+    def run(env, policy, opts, **kw):
+        holder["env"] = env
+        return orig_run(env, policy, opts, **kw)
+
+    ev.run_episodes = run
+    try:
+        cov = wc.evaluate_full_workspace_coverage(approach_policy=Servo(), approach_cfg=acfg, finisher_policy=Servo(), finisher_cfg=fcfg,
+                                                  artifact_root=tmp_path, seed=gold["seed"], episodes_per_split=6, stage_samples_per_stage=3,
+                                                  random_target_samples=6, random_start_samples=5, pair_count=64, include_home_stage_eval=False)
+    finally:
+        ev.run_episodes = orig_run
+    for f in ("maps/target_map.jsonl", "maps/start_state_map.jsonl", "maps/start_target_pairs.jsonl", "known_random_start_eval_summary.json",
+              "workspace_bucket_metrics.json", "full_workspace_coverage_summary.json", "workspace_failure_report.json"):
+        assert (tmp_path / f).exists(), f
+    assert cov["pair_sampler_summary"]["pair_count"] == 64
+    targets = {json.loads(l)["target_id"]: json.loads(l) for l in (tmp_path / "maps/target_map.jsonl").read_text().splitlines()}
+    starts = {json.loads(l)["start_id"]: json.loads(l) for l in (tmp_path / "maps/start_state_map.jsonl").read_text().splitlines()}
+    rows = json.loads((tmp_path / "stress_random_start_eval_summary.json").read_text())["episode_rows"]
+    r = acfg.c.reward
+    for row in rows:
+        s, t = starts[row["start_id"]], targets[row["target_id"]]
+        opts = {"initial_q": np.array(s["q_start"]), "initial_dq": np.array(s["dq_start"]), "initial_prev_action": np.array(s["prev_action"]),
+                "goal_q": np.array(t["q_target"]), "goal_pose6": np.array([*t["ee_target_position"], *t["ee_target_orientation"]]), "policy_mode": "approach"}
+        a_res = _serial_oracle_episode(acfg, opts, gain, r, 2)
+        # fp32 device env vs fp64 oracle over a whole closed-loop episode
+        assert abs(row["approach_final_position_error"] - a_res["pos"]) <= 5e-5, (row["pair_id"], row["approach_final_position_error"], a_res["pos"])
+        assert abs(row["approach_final_orientation_error"] - a_res["ori"]) <= 5e-4
+        if a_res["max_streak"] >= 2:
+            assert row["finisher_ready_dwell"] and row["finisher_ready_hit"]
