@@ -23,7 +23,8 @@ MAX_COMPONENTS = 64
 def build(force: bool = False) -> Path:
     if force or not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < max(
         (HERE / "kp1_oracle.c").stat().st_mtime, (HERE / "kp1_oracle.h").stat().st_mtime,
-        (HERE.parent / "include" / "kp1.h").stat().st_mtime,
+        (HERE / "kp1_route_oracle.c").stat().st_mtime, (HERE / "kp1_route_oracle.h").stat().st_mtime,
+        (HERE.parent / "include" / "kp1.h").stat().st_mtime, (HERE.parent / "include" / "kp1_route.h").stat().st_mtime,
     ):
         subprocess.run(["make", "-C", str(HERE)], check=True, capture_output=True)
     return LIB_PATH
