@@ -1297,3 +1297,5 @@ int kp1_fk_pose6(int32_t device, int32_t real_type, const void* q_dev, void* pos
 }
 
 }  // extern "C"
+
+#include "kp1_route.inc"
