@@ -82,6 +82,9 @@ typedef struct kp1_route_reset_opts {
   const double* initial_q;          /* [N][7] (sequence env only) or NULL = waypoint(start).q_goal */
   const double* initial_dq;         /* [N][7] or NULL = 0 */
   const double* initial_prev_action;
+  int32_t evaluator_state;          /* != 0: honour initial_q / initial_dq / initial_prev_action in the single-waypoint env too -- what
+                                       eval_route_curriculum.py:62-83 does by resetting base_env and poking _route_index / _prev_info */
+  int32_t pad_;
 } kp1_route_reset_opts;
 int kp1_route_reset(kp1_route* r, const uint8_t* mask, const kp1_route_reset_opts* opts, float* obs);
 /* actions [N][7] (f32 or f64 like the base env); obs [N][obs_dim()]; reward [N]; done [N] KP1_DONE_* bits (SUCCESS = route /

@@ -1,0 +1,262 @@
+"""Route prefix curriculum and the sequential route evaluator on the device engine.
+
+Mirror of kinematic_phase1/route/route_curriculum.py:17-136 (``RoutePrefixCurriculumCallback``, ``build_prefix_stages``) and
+kinematic_phase1/eval/eval_route_curriculum.py:57-248 (``_roll_one``, ``_summarize_rows``, ``_failure_reason``, ``_chunk_metrics``,
+``evaluate_sequential_route``).  The callback is a plain object fed with the vectorised env's (done, info) arrays in env order --
+what SB3 hands ``_on_step`` -- and calls ``env.set_route_window`` on promotion.  The sequential evaluator chains the final
+(q, dq, prev_action) of waypoint k into waypoint k+1, so it is serial by construction: one device env, one step per launch pair.
+"""
+from __future__ import annotations
+
+import json
+from collections import deque
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Any, Callable, Sequence
+
+import numpy as np
+import torch
+
+from . import config as kcfg
+from . import route_config as rcfg
+from .route_env import RouteVecEnv
+
+
+@dataclass(frozen=True)
+class RouteCurriculumStage:
+    name: str
+    prefix_end_index: int
+
+
+def build_prefix_stages(prefixes: Sequence[int]) -> list[RouteCurriculumStage]:
+    return [RouteCurriculumStage(name=f"prefix_{int(p)}", prefix_end_index=int(p)) for p in prefixes]
+
+
+class RoutePrefixCurriculum:
+    def __init__(self, *, stages: list[RouteCurriculumStage], promotion_success_rate: float, promotion_route_ready_hit_rate: float,
+                 promotion_orientation_hit_rate: float, promotion_max_regression_rate: float, window_episodes: int, min_episodes_per_stage: int = 128) -> None:
+        if not stages:
+            raise ValueError("RoutePrefixCurriculumCallback requires at least one stage")
+        self.stages = list(stages)
+        self.promotion_success_rate = float(promotion_success_rate)
+        self.promotion_route_ready_hit_rate = float(promotion_route_ready_hit_rate)
+        self.promotion_orientation_hit_rate = float(promotion_orientation_hit_rate)
+        self.promotion_max_regression_rate = float(promotion_max_regression_rate)
+        self.window_episodes = max(int(window_episodes), 1)
+        self.min_episodes_per_stage = max(int(min_episodes_per_stage), 1)
+        self.current_stage_index = 0
+        self.stage_episode_count = 0
+        self.successes: deque[int] = deque(maxlen=self.window_episodes)
+        self.ready_hits: deque[int] = deque(maxlen=self.window_episodes)
+        self.orientation_hits: deque[int] = deque(maxlen=self.window_episodes)
+        self.regressions: deque[int] = deque(maxlen=self.window_episodes)
+        self.history: list[dict[str, object]] = []
+        self.num_timesteps = 0
+        self.training_env: Any = None
+
+    @classmethod
+    def from_config(cls, cfg: dict[str, Any], n_waypoints: int) -> "RoutePrefixCurriculum":
+        """train_route_curriculum.py:86-88, 150-160"""
+        cur = (cfg.get("route", {}) or {}).get("curriculum", {}) or {}
+        return cls(stages=build_prefix_stages(rcfg.prefix_stages(cfg, n_waypoints)), promotion_success_rate=float(cur.get("promotion_success_rate", 0.80)),
+                   promotion_route_ready_hit_rate=float(cur.get("promotion_route_ready_hit_rate", 0.80)),
+                   promotion_orientation_hit_rate=float(cur.get("promotion_orientation_hit_rate", 0.90)),
+                   promotion_max_regression_rate=float(cur.get("promotion_max_regression_rate", 0.20)),
+                   window_episodes=int(cur.get("promotion_window_episodes", 256)), min_episodes_per_stage=int(cur.get("min_episodes_per_stage", 128)))
+
+    def _apply_stage(self) -> None:
+        stage = self.stages[self.current_stage_index]
+        self.training_env.env_method("set_route_window", max_route_index=int(stage.prefix_end_index), min_route_index=1)
+
+    def on_training_start(self, env: Any) -> None:
+        self.training_env = env
+        self._apply_stage()
+
+    def _metrics(self) -> dict[str, float]:
+        def mean(xs: deque[int]) -> float:
+            return float(sum(xs)) / float(len(xs)) if xs else 0.0
+
+        return {"recent_success_rate": mean(self.successes), "recent_route_ready_hit_rate": mean(self.ready_hits),
+                "recent_orientation_hit_rate": mean(self.orientation_hits), "recent_regression_rate": mean(self.regressions)}
+
+    def _promote(self, metrics: dict[str, float]) -> None:
+        if self.current_stage_index >= len(self.stages) - 1:
+            return
+        prev = self.stages[self.current_stage_index]
+        self.current_stage_index += 1
+        nxt = self.stages[self.current_stage_index]
+        self.history.append({"from_stage": prev.name, "to_stage": nxt.name, "from_prefix_end_index": int(prev.prefix_end_index),
+                             "to_prefix_end_index": int(nxt.prefix_end_index), "total_timesteps": int(self.num_timesteps), **metrics})
+        self.stage_episode_count = 0
+        for d in (self.successes, self.ready_hits, self.orientation_hits, self.regressions):
+            d.clear()
+        self._apply_stage()
+
+    def on_step(self, dones: Sequence[Any], success: Sequence[Any], route_ready: Sequence[Any], orientation_hit: Sequence[Any],
+                regression: Sequence[Any]) -> bool:
+        """_on_step over one vectorised step (arrays in env order; ``dones`` = terminated | truncated)."""
+        self.num_timesteps += len(dones)
+        for i, done in enumerate(dones):
+            if not done:
+                continue
+            self.stage_episode_count += 1
+            self.successes.append(1 if bool(success[i]) else 0)
+            self.ready_hits.append(1 if bool(route_ready[i]) else 0)
+            self.orientation_hits.append(1 if bool(orientation_hit[i]) else 0)
+            self.regressions.append(1 if bool(regression[i]) else 0)
+            if self.stage_episode_count < self.min_episodes_per_stage or len(self.successes) < self.window_episodes:
+                continue
+            m = self._metrics()
+            if (m["recent_success_rate"] >= self.promotion_success_rate and m["recent_route_ready_hit_rate"] >= self.promotion_route_ready_hit_rate
+                    and m["recent_orientation_hit_rate"] >= self.promotion_orientation_hit_rate
+                    and m["recent_regression_rate"] <= self.promotion_max_regression_rate):
+                self._promote(m)
+        return True
+
+    def observe_env(self, env: RouteVecEnv) -> bool:
+        """on_step with the device env's last step (done bits + info arrays copied to the host)."""
+        done = env.done.cpu().numpy()
+        info = env.info()
+        return self.on_step((done & 3) != 0, (done & 4) != 0, info["route_ready"].cpu().numpy(), info["route_orientation_hit"].cpu().numpy(),
+                            info["route_regression"].cpu().numpy())
+
+    def summary(self) -> dict[str, object]:
+        stage = self.stages[self.current_stage_index]
+        return {"stage_index": int(self.current_stage_index), "stage_name": stage.name, "prefix_end_index": int(stage.prefix_end_index),
+                "stage_episode_count": int(self.stage_episode_count), **self._metrics(), "history": list(self.history)}
+
+
+# --------------------------------------------------------------------------------------------- sequential evaluator
+PolicyFn = Callable[[torch.Tensor], torch.Tensor]
+
+
+def _roll_one(env: RouteVecEnv, policy: PolicyFn, *, initial_q: np.ndarray, goal_index: int, initial_dq: np.ndarray, initial_prev_action: np.ndarray,
+              success_dwell_steps: int) -> dict[str, Any]:
+    obs = env.reset(options={"route_index": int(goal_index), "start_route_index": 0, "initial_q": initial_q[None], "initial_dq": initial_dq[None],
+                             "initial_prev_action": initial_prev_action[None], "evaluator_state": True})
+    info = env.info()
+    min_pos = float(info["position_error_norm"][0])
+    min_ori = float(info["orientation_error_norm"][0])
+    min_q = float(np.linalg.norm(env.route_q[min(max(goal_index, 0), env.n_waypoints - 1)] - env.get_state()["q"][0]))
+    first_ready_step = None
+    max_ready_streak = 0
+    steps = 0
+    done = 0
+    while not (done & 3):
+        action = policy(obs)
+        obs, _, d = env.step(action, auto_reset=False)
+        done = int(d[0])
+        steps += 1
+        info = env.info()
+        min_pos = min(min_pos, float(info["position_error_norm"][0]))
+        min_ori = min(min_ori, float(info["orientation_error_norm"][0]))
+        min_q = min(min_q, float(info["route_q_error_norm"][0]))
+        if bool(info["route_ready"][0]) and first_ready_step is None:
+            first_ready_step = steps
+        max_ready_streak = max(max_ready_streak, int(info["route_ready_streak"][0]))
+    st = env.get_state()
+    return {
+        "route_index": int(goal_index), "success": bool(done & 4), "route_ready_hit": bool(first_ready_step is not None),
+        "route_ready_dwell": bool(max_ready_streak >= success_dwell_steps), "first_ready_step": first_ready_step, "max_ready_streak": int(max_ready_streak),
+        "steps": int(steps), "final_position_error": float(info["position_error_norm"][0]),
+        "final_orientation_error": float(info["orientation_error_norm"][0]), "final_q_error": float(info["route_q_error_norm"][0]),
+        "min_position_error": float(min_pos), "min_orientation_error": float(min_ori), "min_q_error": float(min_q),
+        "final_action_magnitude": float(info["action_l2"][0]), "final_dq_norm": float(info["executed_delta_q_l2"][0]),
+        "final_q": st["q"][0].copy(), "final_dq": st["dq"][0].copy(), "final_prev_action": st["prev_action"][0].copy(),
+    }
+
+
+def _failure_reason(row: dict[str, Any]) -> str:
+    if row["final_position_error"] > 0.010:
+        return "position"
+    if row["final_orientation_error"] > 0.150:
+        return "orientation"
+    if row.get("final_action_magnitude", 0.0) > 1.20 or row.get("final_dq_norm", 0.0) > 0.040:
+        return "motion_action"
+    if row["final_q_error"] > 0.500:
+        return "q_error"
+    if not row["route_ready_dwell"]:
+        return "dwell_or_motion"
+    return "unknown"
+
+
+def summarize_rows(rows: list[dict[str, Any]], route_progress_m: np.ndarray) -> dict[str, Any]:
+    if not rows:
+        return {"target_count": 0}
+    first_failure = next((row for row in rows if not row["success"]), None)
+    longest_prefix = 0
+    for row in rows:
+        if row["success"]:
+            longest_prefix += 1
+        else:
+            break
+    prefix_end = min(longest_prefix, len(route_progress_m) - 1)
+    return {
+        "target_count": len(rows), "success_rate": float(np.mean([row["success"] for row in rows])),
+        "route_ready_hit_rate": float(np.mean([row["route_ready_hit"] for row in rows])),
+        "route_ready_dwell_rate": float(np.mean([row["route_ready_dwell"] for row in rows])), "longest_success_prefix": int(longest_prefix),
+        "cumulative_successful_route_distance_m": float(route_progress_m[prefix_end] - route_progress_m[0]),
+        "first_failure_index": None if first_failure is None else int(first_failure["route_index"]),
+        "first_failure_reason": None if first_failure is None else _failure_reason(first_failure),
+        "mean_final_position_error": float(np.mean([row["final_position_error"] for row in rows])),
+        "mean_final_orientation_error": float(np.mean([row["final_orientation_error"] for row in rows])),
+        "mean_final_q_error": float(np.mean([row["final_q_error"] for row in rows])),
+        "max_final_position_error": float(np.max([row["final_position_error"] for row in rows])),
+        "max_final_orientation_error": float(np.max([row["final_orientation_error"] for row in rows])),
+    }
+
+
+def chunk_metrics(rows: list[dict[str, Any]]) -> dict[str, Any]:
+    chunks = [(1, 40), (41, 80), (81, 120), (121, 180), (181, 260), (261, 360), (361, 483)]
+    out: dict[str, Any] = {}
+    for idx, (lo, hi) in enumerate(chunks):
+        subset = [row for row in rows if lo <= row["route_index"] <= hi]
+        if not subset:
+            continue
+        out[f"chunk_{idx}_{lo}_{hi}"] = {
+            "target_count": len(subset), "success_rate": float(np.mean([row["success"] for row in subset])),
+            "route_ready_hit_rate": float(np.mean([row["route_ready_hit"] for row in subset])),
+            "mean_final_position_error": float(np.mean([row["final_position_error"] for row in subset])),
+            "mean_final_orientation_error": float(np.mean([row["final_orientation_error"] for row in subset])),
+            "mean_final_q_error": float(np.mean([row["final_q_error"] for row in subset])),
+        }
+    return out
+
+
+def evaluate_sequential_route(*, policy: PolicyFn | Callable[[RouteVecEnv], PolicyFn], cfg: dict[str, Any], route_q: np.ndarray,
+                              artifact_root: str | Path | None = None, end_index: int | None = None, start_index: int = 1, device: int = 0,
+                              real: str = "f32", policy_needs_env: bool = False) -> dict[str, Any]:
+    """evaluate_sequential_route with the policy passed as a callable obs[1, obs_dim] -> action[1, 7] (checkpoint loading is the
+    caller's).  Always the single-waypoint env (``_make_route_env``), whatever ``route.sequence`` says."""
+    W = int(route_q.shape[0])
+    final_end = min(int(end_index or (W - 1)), W - 1)
+    seq_off = {**cfg, "route": {**(cfg.get("route", {}) or {}), "sequence": {**((cfg.get("route", {}) or {}).get("sequence", {}) or {}), "enabled": False}}}
+    base = kcfg.to_env_config(cfg)
+    env = RouteVecEnv(base, rcfg.route_config_from_dict(seq_off, max_route_index=end_index or (W - 1)), route_q, 1, device=device, seed=0, real=real)
+    fn = policy(env) if policy_needs_env else policy
+    rows: list[dict[str, Any]] = []
+    cq = np.asarray(route_q[max(start_index - 1, 0)], dtype=float).copy()
+    cdq = np.zeros_like(cq)
+    cpa = np.zeros_like(cq)
+    dwell = int(base.c.termination.success_dwell_steps)
+    for idx in range(int(start_index), final_end + 1):
+        row = _roll_one(env, fn, initial_q=cq, goal_index=idx, initial_dq=cdq, initial_prev_action=cpa, success_dwell_steps=dwell)
+        rows.append({k: v for k, v in row.items() if k not in {"final_q", "final_dq", "final_prev_action"}})
+        cq, cdq, cpa = row["final_q"], row["final_dq"], row["final_prev_action"]
+    progress = env.route_progress_m.copy()
+    env.close()
+    summary = summarize_rows(rows, progress)
+    summary.update({"schema_version": "v5.route_curriculum.sequential_eval.v1", "mode": "sequential_actual_final_q_to_next_dense_q_goal",
+                    "start_index": int(start_index), "end_index": int(final_end)})
+    if artifact_root is not None:
+        root = Path(artifact_root)
+        root.mkdir(parents=True, exist_ok=True)
+        (root / "route_eval_sequential_summary.json").write_text(json.dumps(summary, indent=2))
+        (root / "route_chunk_metrics.json").write_text(json.dumps(chunk_metrics(rows), indent=2))
+        with (root / "route_eval_sequential_steps.jsonl").open("w", encoding="utf-8") as fh:
+            for row in rows:
+                fh.write(json.dumps(row, sort_keys=True) + "\n")
+        failure = next((row for row in rows if not row["success"]), None)
+        (root / "route_failure_report.json").write_text(json.dumps({"first_failure_index": summary["first_failure_index"],
+                                                                    "first_failure_reason": summary["first_failure_reason"], "first_failure": failure}, indent=2))
+    return {**summary, "rows": rows, "chunk_metrics": chunk_metrics(rows), "final_q": np.asarray(cq).tolist()}

@@ -23,7 +23,7 @@ from .vec_env import ArmKinematicVecEnv, _view
 
 class _RouteResetOpts(C.Structure):
     _fields_ = [("route_index", C.c_void_p), ("start_route_index", C.c_void_p), ("initial_q", C.c_void_p), ("initial_dq", C.c_void_p),
-                ("initial_prev_action", C.c_void_p)]
+                ("initial_prev_action", C.c_void_p), ("evaluator_state", C.c_int32), ("pad_", C.c_int32)]
 
 
 class _RouteInfoView(C.Structure):
@@ -120,7 +120,8 @@ class RouteVecEnv:
         native.check(self.L.kp1_route_seed(self._handle, int(seed), int(first_env_id)))
 
     def reset(self, *, seed: int | None = None, options: dict[str, Any] | None = None, mask: torch.Tensor | None = None) -> torch.Tensor:
-        """options: {"route_index": int | [N], "start_route_index", "initial_q" [N,7], "initial_dq", "initial_prev_action"} or None = sample."""
+        """options: {"route_index": int | [N], "start_route_index", "initial_q" [N,7], "initial_dq", "initial_prev_action"} or None = sample.
+        ``evaluator_state=True`` makes the single-waypoint env honour the initial state too (the sequential evaluator's chained resets)."""
         if seed is not None:
             self.seed(seed)
         opts = None
@@ -143,6 +144,7 @@ class RouteVecEnv:
             opts.start_route_index = ints(options["start_route_index"]) if "start_route_index" in options else None
             for key in ("initial_q", "initial_dq", "initial_prev_action"):
                 setattr(opts, key, mats(options[key]) if key in options else None)
+            opts.evaluator_state = int(bool(options.get("evaluator_state", False)))
         m = None
         if mask is not None:
             m = mask.to(device=self.device, dtype=torch.uint8).contiguous()

@@ -1,0 +1,95 @@
+"""Route prefix curriculum (CPU) and sequential route evaluator (GPU) against the reference's outputs in tests/golden/route_eval.json
+(tests/golden/make_golden_route_eval.py)."""
+from __future__ import annotations
+
+import json
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from rl_brain_trainer_amd import route_config as rcfg
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return json.loads((GOLDEN / "route_eval.json").read_text())
+
+
+class _FakeEnv:
+    def __init__(self):
+        self.calls = []
+
+    def env_method(self, name, **kw):
+        self.calls.append([name, kw])
+
+
+def test_prefix_curriculum_matches_reference_callback(gold):
+    from rl_brain_trainer_amd.route_curriculum import RoutePrefixCurriculum, build_prefix_stages
+
+    for trace in gold["callback"]:
+        cb = RoutePrefixCurriculum(stages=build_prefix_stages([20, 40, 80]), promotion_success_rate=0.75, promotion_route_ready_hit_rate=0.75,
+                                   promotion_orientation_hit_rate=0.85, promotion_max_regression_rate=0.30, window_episodes=16, min_episodes_per_stage=24)
+        env = _FakeEnv()
+        cb.on_training_start(env)
+        for step in trace["steps"]:
+            infos = step["infos"]
+            cb.on_step(step["dones"], [i["success"] for i in infos], [i["route_ready"] for i in infos], [i["route_orientation_hit"] for i in infos],
+                       [i["route_regression"] for i in infos])
+            assert (cb.current_stage_index, cb.stage_episode_count) == (step["stage"], step["count"])
+        assert json.loads(json.dumps(cb.summary())) == trace["summary"]
+        assert env.calls == [list(c) for c in trace["window_calls"]]
+
+
+def test_prefix_stages_and_config_defaults():
+    from rl_brain_trainer_amd.route_curriculum import RoutePrefixCurriculum
+
+    cfg = json.loads((GOLDEN / "configs" / "route_curriculum_prefix120_routeobs_sequence2.json").read_text())
+    assert rcfg.prefix_stages(cfg, 484) == [120]
+    assert rcfg.prefix_stages({}, 484) == [20, 40, 80, 120, 180, 260, 360, 483]
+    cb = RoutePrefixCurriculum.from_config(cfg, 484)
+    assert cb.window_episodes == 256 and cb.min_episodes_per_stage == 1024 and cb.promotion_max_regression_rate == 0.30
+    with pytest.raises(TypeError):
+        rcfg.route_config_from_dict({"route": {"reward": {"nope": 1.0}}})
+
+
+@pytest.mark.gpu
+def test_sequential_route_evaluator_matches_reference(tmp_path, gold):
+    """The reference's _roll_one loop with a scripted servo model vs the device evaluator with the same controller (fp64 env)."""
+    import torch
+
+    from rl_brain_trainer_amd.route_curriculum import evaluate_sequential_route
+
+    cfg = json.loads((GOLDEN / "configs" / "route_curriculum_prefix120_routeobs_sequence2.json").read_text())
+    route_q = rcfg.load_route_q(GOLDEN / "synthetic_route.json")
+    for case in gold["sequential"]:
+        gain = case["gain"]
+
+        def make_policy(env, gain=gain):
+            dl = torch.tensor(env.config.c.joints.delta_limit[:], device="cuda", dtype=torch.float64) * env.config.c.env.action_delta_scale
+            rq = torch.tensor(route_q, device="cuda", dtype=torch.float64)
+
+            def policy(obs):
+                info = env.info()
+                goal = rq[info["route_index"].long()]
+                return (gain * (goal - info["q"].double().t()) / dl).clamp(-1, 1)
+
+            return policy
+
+        out = evaluate_sequential_route(policy=make_policy, policy_needs_env=True, cfg=cfg, route_q=route_q, artifact_root=tmp_path / f"g{gain}",
+                                        start_index=case["start_index"], end_index=case["end_index"], real="f64")
+        assert len(out["rows"]) == len(case["rows"])
+        for mine, ref in zip(out["rows"], case["rows"]):
+            for k, v in ref.items():
+                if isinstance(v, float):
+                    assert abs(mine[k] - v) <= 1e-9 * max(1.0, abs(v)), (case["gain"], ref["route_index"], k, mine[k], v)
+                else:
+                    assert mine[k] == v, (case["gain"], ref["route_index"], k, mine[k], v)
+        for k, v in case["summary"].items():
+            if isinstance(v, float):
+                assert abs(out[k] - v) <= 1e-9 * max(1.0, abs(v)), k
+            else:
+                assert out[k] == v, k
+        assert json.loads(json.dumps(out["chunk_metrics"])).keys() == case["chunk_metrics"].keys()
+        assert np.max(np.abs(np.array(out["final_q"]) - np.array(case["final_q"]))) <= 1e-12
+        assert (tmp_path / f"g{gain}" / "route_eval_sequential_summary.json").exists()
