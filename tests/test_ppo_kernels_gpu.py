@@ -268,3 +268,28 @@ def test_adv_minibatch_sums_vs_torch():
         assert out[b, 2].item() == sel.numel()
         assert abs(out[b, 0].item() - sel.sum().item()) <= 1e-9 * sel.abs().sum().item()
         assert abs(out[b, 1].item() - (sel * sel).sum().item()) <= 1e-9 * (sel * sel).sum().item()
+
+
+def test_compacted_truncation_bootstrap_matches_dense_path():
+    """collect_rollouts' time-limit bootstrap: critic on the truncated steps only (fixed-size index list) vs critic on all T * N
+    terminal observations + kp1_bootstrap_truncated."""
+    from conftest import load_golden_config
+    from rl_brain_trainer_amd.vec_env import ArmKinematicVecEnv
+
+    cfg = load_golden_config("workspace_expansion_bigtrain")
+    env = ArmKinematicVecEnv(cfg, 512, seed=3)
+    env.set_curriculum_stage(5)
+    ppo = P.PPO(env, P.PPOConfig(n_steps=128, batch_size=4096, n_epochs=1, hidden=256, seed=3), backend="hip", use_graphs=False)
+    ppo.collect_rollouts()                      # real done / terminal_obs buffers (96-step episodes: every env truncates once or twice)
+    trunc = ((ppo.done_buf & 3) == 2)
+    assert 512 <= int(trunc.sum()) <= 1024
+    g = torch.Generator(device=DEV).manual_seed(9)
+    raw = torch.randn(ppo.rew_buf.shape, device=DEV, generator=g)
+    ppo.rew_buf.copy_(raw)
+    ppo._bootstrap_truncated(dense=True)
+    dense = ppo.rew_buf.clone()
+    ppo.rew_buf.copy_(raw)
+    ppo._bootstrap_truncated()
+    assert torch.equal((ppo.rew_buf != raw), trunc)
+    assert torch.allclose(ppo.rew_buf, dense, rtol=0, atol=1e-6)
+    env.close()
