@@ -53,6 +53,56 @@ def write_json(path: Path, payload: dict[str, Any]) -> None:
     path.write_text(json.dumps(payload, indent=2))
 
 
+class WorkspaceEvalGate:
+    """WorkspaceEvalGateCallback (train_workspace_expansion.py:54-129): every ``eval_interval`` timesteps save a candidate, run the
+    deterministic Approach -> Finisher stage suites on it, append the gated selection to eval_history.jsonl and keep the best
+    retention-ok candidate as best_checkpoint/model_best_by_gate.zip.  The reference checks after every env step of its 12-16
+    envs; here the check runs after every PPO iteration (n_envs * n_steps timesteps), so evaluations land on iteration boundaries."""
+
+    def __init__(self, *, artifact_root: Path, approach_cfg: kcfg.EnvConfig, finisher_policy, finisher_cfg: kcfg.EnvConfig | None, eval_interval: int,
+                 episodes: int, seed: int, stage_indices: list[int], gate_config: dict[str, Any], device: int = 0) -> None:
+        self.artifact_root = artifact_root
+        self.approach_cfg, self.finisher_policy, self.finisher_cfg = approach_cfg, finisher_policy, finisher_cfg
+        self.eval_interval = max(int(eval_interval), 1)
+        self.episodes = max(int(episodes), 1)
+        self.seed = int(seed)
+        self.stage_indices = list(stage_indices)
+        self.gate_config = dict(gate_config)
+        self.device = device
+        self.candidates_dir = artifact_root / "gate_candidates"
+        self.eval_dir = artifact_root / "gate_evals"
+        self.best_dir = artifact_root / "best_checkpoint"
+        self.eval_history_path = artifact_root / "eval_history.jsonl"
+        for d in (self.candidates_dir, self.eval_dir, self.best_dir):
+            d.mkdir(parents=True, exist_ok=True)
+        self.best_score = float("-inf")
+        self.next_eval_timesteps = self.eval_interval
+
+    def on_iteration(self, ppo: PPO, env_cfg: kcfg.EnvConfig) -> dict[str, Any] | None:
+        from . import evaluate as ev
+
+        if ppo.num_timesteps < self.next_eval_timesteps:
+            return None
+        while self.next_eval_timesteps <= ppo.num_timesteps:
+            self.next_eval_timesteps += self.eval_interval
+        candidate = self.candidates_dir / f"candidate_step_{ppo.num_timesteps}"
+        checkpoint.save(candidate, ppo, env_cfg)
+        summary = ev.evaluate_workspace_expansion(approach_policy=ppo.predict, finisher_policy=self.finisher_policy, approach_cfg=self.approach_cfg,
+                                                  finisher_cfg=self.finisher_cfg, episodes=self.episodes, seed=self.seed, stage_indices=self.stage_indices,
+                                                  gate_config=self.gate_config, artifact_root=self.eval_dir / f"eval_step_{ppo.num_timesteps}",
+                                                  device=self.device, obs_stride=ppo.obs_w)
+        selection = summary["best_model_selection"]
+        record = {"timesteps": int(ppo.num_timesteps), "candidate": str(candidate) + ".zip", **selection}
+        with self.eval_history_path.open("a", encoding="utf-8") as handle:
+            handle.write(json.dumps(record) + "\n")
+        score = float(selection["score"])
+        if bool(selection["retention_ok"]) and score > self.best_score:
+            self.best_score = score
+            checkpoint.save(self.best_dir / "model_best_by_gate", ppo, env_cfg)
+            write_json(self.artifact_root / "best_model_selection_summary.json", record)
+        return record
+
+
 def main(argv: list[str] | None = None) -> dict[str, Any]:
     args = build_arg_parser().parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,9 +157,33 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
         if rank == 0:
             print(f"Resuming workspace expansion from {resume}")
 
+    gate = None
+    finisher_policy = finisher_cfg = None
+    gate_cfg = dict(ws.get("gate", {}) or {})
+    if ws.get("finisher_checkpoint") and Path(str(ws["finisher_checkpoint"])).exists():
+        from .ppo import InferencePolicy
+
+        finisher_policy = InferencePolicy.load(str(ws["finisher_checkpoint"]), device=local_rank)
+        finisher_cfg = kcfg.to_env_config(kcfg.load_yaml_file(ws["finisher_config"]), handoff_base_dirs=(Path(str(ws["finisher_config"])).parent,))
+    if rank == 0 and not args.no_gate_callback and finisher_policy is not None:
+        gate = WorkspaceEvalGate(artifact_root=root, approach_cfg=env_cfg, finisher_policy=finisher_policy, finisher_cfg=finisher_cfg,
+                                 eval_interval=int(ws.get("eval_interval", 200_000)), episodes=int(ws.get("gate_eval_episodes", 24)),
+                                 seed=int(ws.get("eval_seed", 700001)), stage_indices=list(range(env_cfg.n_stages)), gate_config=gate_cfg,
+                                 device=local_rank)
+
     t0 = time.time()
     total = int(algo.get("total_timesteps", 100_000))
-    ppo.learn(total, log_every=args.log_every)
+    start_steps, it = ppo.num_timesteps, 0
+    while ppo.num_timesteps - start_steps < total:     # PPO.learn, one iteration at a time so the gate can look in between
+        ppo.collect_rollouts()
+        ppo.train()
+        it += 1
+        if gate is not None:
+            gate.on_iteration(ppo, env_cfg)
+        if args.log_every and it % args.log_every == 0 and rank == 0:
+            stage = curriculum.read().stage_index if curriculum is not None else -1
+            print(f"[ppo] it={it} steps={ppo.num_timesteps} fps={(ppo.num_timesteps - start_steps) / (time.time() - t0):,.0f} stage={stage} "
+                  f"rew={ppo.rew_buf.mean().item():.4f} {ppo.last_stats}", flush=True)
     torch.cuda.synchronize()
     wall = time.time() - t0
     summary: dict[str, Any] = {}
@@ -117,11 +191,23 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
         latest = root / "latest_checkpoint" / "model_latest"
         checkpoint.save(latest, ppo, env_cfg)
         checkpoint.save(root / "model_latest", ppo, env_cfg)
+        final_eval = None
+        if finisher_policy is not None:   # train_workspace_expansion.py:243-259
+            from . import evaluate as ev
+
+            final_eval = ev.evaluate_workspace_expansion(approach_policy=ppo.predict, finisher_policy=finisher_policy, approach_cfg=env_cfg,
+                                                         finisher_cfg=finisher_cfg, episodes=int(ws.get("final_eval_episodes", 80)),
+                                                         seed=int(ws.get("eval_seed", 700001)), stage_indices=list(range(env_cfg.n_stages)),
+                                                         gate_config=gate_cfg, artifact_root=root / "final_eval", device=local_rank, obs_stride=ppo.obs_w)
+            final_eval = {k: v for k, v in final_eval.items() if k != "target_rows"}
+            for name in ("stage_metrics.json", "workspace_failure_report.json", "best_model_selection_summary.json"):
+                if (root / "final_eval" / name).exists():
+                    shutil.copyfile(root / "final_eval" / name, root / name)
         summary = {
             "policy_type": "approach", "algorithm": "ppo", "run_id": args.run_id, "model_path": str(latest) + ".zip",
             "resume_from": str(resume) if resume else None, "n_envs": n_envs * world, "device": f"{world}x MI355X",
             "curriculum_summary": curriculum.summary() if curriculum is not None else None,
-            "final_workspace_eval": None, "num_timesteps": ppo.num_timesteps, "wall_seconds": wall,
+            "final_workspace_eval": final_eval, "num_timesteps": ppo.num_timesteps, "wall_seconds": wall,
             "env_steps_per_second": ppo.num_timesteps / wall, "last_update_stats": ppo.last_stats,
         }
         write_json(root / "training_summary.json", summary)
