@@ -1,0 +1,61 @@
+"""Train the Approach policy from scratch through the point curriculum (stages 0 -> 5) on one MI355X and evaluate stage 5.
+
+    python tools/convergence_run.py [total_timesteps] [learning_rate] [out_json]
+
+BASELINE.md quotes 0.93 success / 2.89 mm at stage 5 for the reference after its multi-stage fine-tuning schedule; this script is
+the engine's own end-to-end evidence that rollout, curriculum tracker, fused MFMA update and evaluator learn the task."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from rl_brain_trainer_amd import config as kcfg
+from rl_brain_trainer_amd import evaluate as ev
+from rl_brain_trainer_amd.curriculum import PointCurriculum
+from rl_brain_trainer_amd.ppo import PPO, PPOConfig
+from rl_brain_trainer_amd.vec_env import ArmKinematicVecEnv
+
+total = int(float(sys.argv[1])) if len(sys.argv) > 1 else 200_000_000
+lr = float(sys.argv[2]) if len(sys.argv) > 2 else 3e-4
+out = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/convergence.json"
+cfg_dict = kcfg.load_workspace_expansion_config(kcfg.builtin_config_dir() / "workspace_expansion_bigtrain.yaml")
+cfg_dict["env"]["curriculum"]["stages"] = cfg_dict["env"]["curriculum"]["stages"][:6]      # stages 0..5 (SURVEY config 2 pins stage 5)
+env_cfg = kcfg.to_env_config(cfg_dict)
+cur = cfg_dict["env"]["curriculum"]
+N = 4096
+env = ArmKinematicVecEnv(env_cfg, N, seed=806)
+curriculum = PointCurriculum(success_rate_threshold=float(cur["success_rate_threshold"]), window_episodes=int(cur["window_episodes"]),
+                             min_episodes_per_stage=int(cur["min_episodes_per_stage"]), max_stage_index=5, initial_stage_index=0, device=0)
+epochs = int(os.environ.get("KP1_EPOCHS", "8"))
+clip = float(os.environ.get("KP1_CLIP", "0.1"))
+ent = float(os.environ.get("KP1_ENT", "3e-4"))
+batch = int(os.environ.get("KP1_BATCH", "8192"))
+ppo = PPO(env, PPOConfig(n_steps=128, batch_size=batch, n_epochs=epochs, hidden=256, learning_rate=lr, gamma=0.995, gae_lambda=0.95, clip_range=clip, ent_coef=ent,
+                         seed=806), curriculum=curriculum, backend="hip")
+t0 = time.time()
+log = []
+it = 0
+while ppo.num_timesteps < total:
+    ppo.collect_rollouts()
+    ppo.train()
+    it += 1
+    if it % 20 == 0:
+        st = curriculum.read()
+        rec = {"it": it, "steps": ppo.num_timesteps, "wall_s": round(time.time() - t0, 1), "stage": int(st.stage_index), "reward_mean": float(ppo.rew_buf.mean()),
+               **{k: round(v, 5) if isinstance(v, float) else v for k, v in ppo.last_stats.items()}}
+        log.append(rec)
+        print(json.dumps(rec), flush=True)
+torch.cuda.synchronize()
+wall = time.time() - t0
+res = ev.evaluate_workspace_expansion(approach_policy=ppo.predict, finisher_policy=None, approach_cfg=env_cfg, finisher_cfg=None, episodes=200, seed=700001,
+                                      stage_indices=[0, 1, 2, 3, 4, 5], gate_config=cfg_dict["workspace_expansion"]["gate"], obs_stride=ppo.obs_w)
+summary = {"hyper": {"epochs": epochs, "clip": clip, "ent_coef": ent, "batch": batch}, "total_timesteps": ppo.num_timesteps, "wall_seconds": wall, "env_steps_per_second": ppo.num_timesteps / wall, "learning_rate": lr,
+           "final_stage": int(curriculum.read().stage_index), "curriculum": curriculum.summary(),
+           "stage_metrics": {k: {m: v[m] for m in ("success_rate", "mean_final_position_error", "mean_final_orientation_error")} for k, v in res["stage_metrics"].items()},
+           "log": log}
+os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+json.dump(summary, open(out, "w"), indent=1)
+print(json.dumps({k: summary[k] for k in ("total_timesteps", "wall_seconds", "final_stage", "stage_metrics")}, indent=1))
