@@ -21,14 +21,19 @@ from rl_brain_trainer_amd.vec_env import ArmKinematicVecEnv
 total = int(float(sys.argv[1])) if len(sys.argv) > 1 else 200_000_000
 lr = float(sys.argv[2]) if len(sys.argv) > 2 else 3e-4
 out = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/convergence.json"
-cfg_dict = kcfg.load_workspace_expansion_config(kcfg.builtin_config_dir() / "workspace_expansion_bigtrain.yaml")
-cfg_dict["env"]["curriculum"]["stages"] = cfg_dict["env"]["curriculum"]["stages"][:6]      # stages 0..5 (SURVEY config 2 pins stage 5)
+if os.environ.get("KP1_CONFIG", "bigtrain") == "approach_default":   # BASELINE config 1: 20-step episodes, terminate on success, default stages 0..5
+    cfg_dict = kcfg.deep_merge(kcfg.load_yaml_file(kcfg.builtin_config_dir() / "approach_default.yaml"), kcfg.load_yaml_file(kcfg.builtin_config_dir() / "ppo_default.yaml"))
+    cfg_dict.setdefault("workspace_expansion", {}).setdefault("gate", {})
+else:
+    cfg_dict = kcfg.load_workspace_expansion_config(kcfg.builtin_config_dir() / "workspace_expansion_bigtrain.yaml")
+    cfg_dict["env"]["curriculum"]["stages"] = cfg_dict["env"]["curriculum"]["stages"][:6]      # stages 0..5 (SURVEY config 2 pins stage 5)
 env_cfg = kcfg.to_env_config(cfg_dict)
 cur = cfg_dict["env"]["curriculum"]
 N = 4096
 env = ArmKinematicVecEnv(env_cfg, N, seed=806)
-curriculum = PointCurriculum(success_rate_threshold=float(cur["success_rate_threshold"]), window_episodes=int(cur["window_episodes"]),
-                             min_episodes_per_stage=int(cur["min_episodes_per_stage"]), max_stage_index=5, initial_stage_index=0, device=0)
+curriculum = PointCurriculum(success_rate_threshold=float(cur.get("success_rate_threshold", 0.8)), window_episodes=int(cur.get("window_episodes", 20)),
+                             min_episodes_per_stage=int(cur.get("min_episodes_per_stage", 30)), max_stage_index=min(5, env_cfg.n_stages - 1), initial_stage_index=0,
+                             device=0)
 epochs = int(os.environ.get("KP1_EPOCHS", "8"))
 clip = float(os.environ.get("KP1_CLIP", "0.1"))
 ent = float(os.environ.get("KP1_ENT", "3e-4"))
@@ -50,8 +55,15 @@ while ppo.num_timesteps < total:
         print(json.dumps(rec), flush=True)
 torch.cuda.synchronize()
 wall = time.time() - t0
+done = ppo.done_buf
+train_success = float(((done & 4) != 0).sum()) / max(float(((done & 3) != 0).sum()), 1.0)
+print("training-time success rate of the last rollout:", train_success, "episodes", int(((done & 3) != 0).sum()), flush=True)
+res_s = ev.evaluate_workspace_expansion(approach_policy=lambda o: ppo.predict(o, deterministic=False), finisher_policy=None, approach_cfg=env_cfg,
+                                        finisher_cfg=None, episodes=200, seed=700001, stage_indices=list(range(min(6, env_cfg.n_stages))),
+                                        gate_config=cfg_dict["workspace_expansion"]["gate"], obs_stride=ppo.obs_w)
+print("stochastic eval:", {k: (v["success_rate"], round(v["mean_final_position_error"], 4)) for k, v in res_s["stage_metrics"].items()}, flush=True)
 res = ev.evaluate_workspace_expansion(approach_policy=ppo.predict, finisher_policy=None, approach_cfg=env_cfg, finisher_cfg=None, episodes=200, seed=700001,
-                                      stage_indices=[0, 1, 2, 3, 4, 5], gate_config=cfg_dict["workspace_expansion"]["gate"], obs_stride=ppo.obs_w)
+                                      stage_indices=list(range(min(6, env_cfg.n_stages))), gate_config=cfg_dict["workspace_expansion"]["gate"], obs_stride=ppo.obs_w)
 summary = {"hyper": {"epochs": epochs, "clip": clip, "ent_coef": ent, "batch": batch}, "total_timesteps": ppo.num_timesteps, "wall_seconds": wall, "env_steps_per_second": ppo.num_timesteps / wall, "learning_rate": lr,
            "final_stage": int(curriculum.read().stage_index), "curriculum": curriculum.summary(),
            "stage_metrics": {k: {m: v[m] for m in ("success_rate", "mean_final_position_error", "mean_final_orientation_error")} for k, v in res["stage_metrics"].items()},
