@@ -226,6 +226,9 @@ class PPO:
         self.use_graphs = bool(use_graphs and backend == "hip" and not self.dist.enabled)
         self._rollout_graph = None
         self._epoch_graph = None
+        # optional host hook after every env step (done bits of that step, device tensor): what SB3 callbacks' _on_step sees.
+        # Setting it makes the rollout eager (a host hook cannot live inside a hipGraph replay).
+        self.step_callback = None
         if self.use_graphs:
             self.noise_all = torch.zeros((T, N, ACT_DIM), dtype=torch.float32, device=dev)
             self.perm = torch.zeros(T * N, dtype=torch.int64, device=dev)
@@ -291,12 +294,13 @@ class PPO:
         log_std = self.policy.views["log_std"]
         std = torch.exp(log_std)
         world = self.dist.world_size
-        if self.use_graphs:
+        graph_rollout = self.use_graphs and self.step_callback is None
+        if graph_rollout:
             self.noise_all.normal_(generator=self.gen)
             if self._rollout_graph is None:
                 self._capture_rollout()
             self._rollout_graph.replay()
-        for t in range(0 if not self.use_graphs else T, T):
+        for t in range(0 if not graph_rollout else T, T):
             if self._mlp is not None:
                 # 3 launches: two MFMA layer GEMMs + the head kernel (heads, sampling, log-prob, clip fused)
                 self.noise.normal_(generator=self.gen)
@@ -314,6 +318,8 @@ class PPO:
             if self.curriculum is not None:
                 dones = self.dist.all_gather_bytes(self.done_buf[t])
                 self.curriculum.observe(dones, N * world)
+            if self.step_callback is not None:
+                self.step_callback(self.done_buf[t])
         self.num_timesteps += T * N * world
         self._bootstrap_truncated()
         stream = torch.cuda.current_stream(self.device).cuda_stream

@@ -47,3 +47,31 @@ def test_train_cli_with_eval_gate_and_final_eval(tmp_path):
     assert ts["final_workspace_eval"]["episodes_per_stage"] == 3 and len(ts["final_workspace_eval"]["stage_metrics"]) == 10
     sd = checkpoint.load_policy_state_dict(root / "model_latest.zip")
     assert sd["mlp_extractor.policy_net.0.weight"].shape == (256, 56)
+
+
+def test_train_dock_cli_with_reverse_curriculum(tmp_path):
+    """Finisher trainer CLI (mirror of train_dock_policy.py) with the dock reverse curriculum on the per-step hook."""
+    import torch
+
+    from rl_brain_trainer_amd import config as kcfg, train_dock
+
+    dock = kcfg.load_yaml_file(kcfg.builtin_config_dir() / "dock_workspace_handoff_noop_ft_12env.yaml")
+    dock["env"]["dock_reset"]["handoff_state_probability"] = 0.0           # the reference's handoff buffer file is not shipped
+    dock.setdefault("training", {})["dock_reverse_curriculum"] = {
+        "enabled": True, "window_episodes": 64,
+        "stages": [{"name": "anchor", "min_episodes": 64, "window_episodes": 64, "success_rate_threshold": 0.0, "dock_residual_action_limit": 0.2,
+                    "close_bucket_probability": 1.0, "close_bucket_min_pos_error_m": 0.001, "close_bucket_max_pos_error_m": 0.004,
+                    "close_bucket_max_ori_error_rad": 0.05},
+                   {"name": "wide", "close_bucket_probability": 0.2, "dock_residual_action_limit": 0.35}]}
+    cfg_path = tmp_path / "dock.yaml"
+    cfg_path.write_text(yaml.safe_dump(dock))
+    root = tmp_path / "dock_run"
+    summary = train_dock.main(["--config", str(cfg_path), "--run-id", "d", "--artifact-root", str(root), "--total-timesteps", "16384", "--n-envs", "256",
+                               "--n-steps", "32", "--batch-size", "1024", "--eval-episodes", "64", "--log-every", "0"])
+    torch.cuda.synchronize()
+    assert summary["num_timesteps"] == 16384 and summary["policy_type"] == "dock"
+    cur = summary["dock_reverse_curriculum"]
+    assert cur["stage_index"] == 1 and cur["history"][0]["from_stage_name"] == "anchor"     # threshold 0: promoted after 64 episodes
+    assert 0.0 <= summary["dock_eval_summary"]["success_rate"] <= 1.0 and summary["dock_eval_summary"]["episodes"] == 64
+    for f in ("model_latest.zip", "training_summary.json", "dock_eval/dock_eval_summary.json"):
+        assert (root / f).exists(), f
