@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -1039,7 +1040,17 @@ int launch_nt(const GemmNT& g, hipStream_t stream) {
 // dW (both nets) = D^T X over n rows: split-B partial tiles into m->slab, then the fixed-order reduce into G
 int launch_tn(kp1_mlp* m, GemmTN t, int n_o_tiles, int slab_cols, float* slab, int* n_chunks_out, hipStream_t stream);
 
-int launch_fused(const FusedArgs& fa, hipStream_t stream) {
+int launch_fused(const FusedArgs& fa_in, hipStream_t stream) {
+  FusedArgs fa = fa_in;
+  static const int stagger_us = [] { const char* e = std::getenv("KP1_FU_STAGGER_US"); return e ? std::atoi(e) : 12; }();  // tuning knob
+  static const int n_cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    return n;
+  }();
+  const int n_wgs = 2 * ((fa.n + FU_BM - 1) / FU_BM);
+  fa.n_cus = n_cus;
+  fa.stagger_ticks = n_wgs > n_cus ? stagger_us * 100 : 0;   // only when CUs hold two workgroups at once
   const size_t bytes = sizeof(float) * FU_LDS_FLOATS;
   HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   hipLaunchKernelGGL(mlp_tile_kernel<true>, dim3((fa.n + FU_BM - 1) / FU_BM, 1, 2), dim3(FU_NTH), bytes, stream, fa);
