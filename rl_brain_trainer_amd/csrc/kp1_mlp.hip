@@ -44,8 +44,17 @@ __device__ unsigned long long kp1_nt_trace_buf[KP1_TRACE_SLOTS * KP1_TRACE_WGS];
     const int wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                           \
     if (wg_ < KP1_TRACE_WGS) kp1_nt_trace_buf[wg_ * KP1_TRACE_SLOTS + (slot)] = wall_clock64();               \
   }
+// where the workgroup runs: HW_ID (cu_id [11:8], sh_id [12], se_id [15:13]) in the low word, XCC_ID in the high word
+#define KP1_TR_HW(slot)                                                                                       \
+  if (threadIdx.x == 0) {                                                                                     \
+    const int wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                           \
+    if (wg_ < KP1_TRACE_WGS)                                                                                  \
+      kp1_nt_trace_buf[wg_ * KP1_TRACE_SLOTS + (slot)] =                                                      \
+          (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); \
+  }
 #else
 #define KP1_TR(slot)
+#define KP1_TR_HW(slot)
 #endif
 
 // Branch-free tanh (the epilogue runs one wave per SIMD, so every VALU slot is exposed; ocml's tanhf costs ~45

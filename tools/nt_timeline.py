@@ -65,6 +65,15 @@ us = (t - t0) / 100.0
 print("workgroups traced:", len(t))
 if tnfrag:
     # the tile kernel's stamps are overwritten by the TN launch that follows it (same buffer, block-linear index)
+    hw = t[:, 11]
+    cu = ((hw >> 32) & 0xF) * 64 + ((hw >> 13) & 0x7) * 16 + ((hw >> 8) & 0xF)      # (xcc, se, cu) -> one id per CU
+    kinds = {}
+    for b in range(min(512, len(t))):
+        kinds.setdefault(int(cu[b]), []).append("dW2" if b < 256 else "dW1")
+    mix = {}
+    for v in kinds.values():
+        mix["+".join(sorted(v))] = mix.get("+".join(sorted(v)), 0) + 1
+    print("CUs used:", len(kinds), " workgroup kinds per CU:", mix)
     for nm, sel in (("dW2 workgroups", us[:256]), ("dW1 workgroups", us[256:512])):
         print(nm, "start / loop done / acc in LDS / stored (median us):", np.round(np.median(sel[:, 12:16], axis=0), 2),
               " max stored", round(float(sel[:, 15].max()), 2), " latest start", round(float(sel[:, 12].max()), 2))
