@@ -81,14 +81,20 @@ int kp1_bind_stage_ptr(kp1_env* env, const int32_t* stage_dev);
  * Kernel-format weights ("kw", see kp1_mlp_pack_weights) hold W1 zero-padded to 64 input columns, W2 and W2^T. */
 #define KP1_MLP_IN 56
 #define KP1_MLP_IN_PAD 64
+#define KP1_MLP_IN_ROUTE 80      /* with the route observation keys (route/route_observation.py:14-61); padded to 128 */
+#define KP1_MLP_IN_ROUTE_PAD 128
 #define KP1_MLP_ACT 7
 
 typedef struct kp1_mlp kp1_mlp; /* workspace: packed weights, activations, gradients for up to max_batch rows */
 
 int kp1_mlp_create(int32_t device, int32_t hidden, int32_t max_batch, kp1_mlp** out);
+/* same, for an observation of obs_dim floats: 56 (ArmKinematicEnv, observation_builder.py:29-94) or 80 (the route wrappers with
+ * include_route_keys, route/route_env.py:186-207).  Rows are read with pitch obs_dim or the padded width (64 / 128). */
+int kp1_mlp_create_ex(int32_t device, int32_t hidden, int32_t obs_dim, int32_t max_batch, kp1_mlp** out);
 int kp1_mlp_destroy(kp1_mlp* m);
 /* number of f32 parameters in SB3 state_dict order (log_std, pi.0.w, pi.0.b, pi.2.w, pi.2.b, vf.0.w, ..., action_net.w/b, value_net.w/b) */
 int64_t kp1_mlp_num_params(int32_t hidden);
+int64_t kp1_mlp_num_params_ex(int32_t hidden, int32_t obs_dim);
 /* repack the flat SB3-order parameter vector into kernel-format weights (call after every optimiser step) */
 int kp1_mlp_pack_weights(kp1_mlp* m, const float* params, void* stream);
 

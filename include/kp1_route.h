@@ -91,6 +91,9 @@ int kp1_route_reset(kp1_route* r, const uint8_t* mask, const kp1_route_reset_opt
  * sequence success); auto_reset != 0 resets finished envs in place after writing terminal_obs (may be NULL) */
 int kp1_route_step(kp1_route* r, const void* actions, float* obs, void* reward, uint8_t* done, float* terminal_obs, int32_t auto_reset);
 int kp1_route_obs_dim(const kp1_route* r);
+/* row pitch of the observation buffers passed to reset / step (default obs_dim; the PPO loop uses the MFMA kernels' padded
+ * widths 64 / 128 -- only the first obs_dim floats of a row are written) */
+int kp1_route_set_obs_stride(kp1_route* r, int32_t stride);
 
 typedef struct kp1_route_info_view {  /* device arrays [N], valid until the next call */
   const int32_t* route_index; const int32_t* start_route_index; const int32_t* last_route_index; const int32_t* reset_mode;

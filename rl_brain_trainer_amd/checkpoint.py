@@ -42,8 +42,13 @@ SB3_VERSION_PIN = "2.8.0"
 def _policy_data(ppo, env_cfg: kcfg.EnvConfig | None) -> dict[str, Any]:
     cfg = ppo.cfg
     H = cfg.hidden
-    obs_space = {k: {"shape": [n], "low": (0.0 if k in ("task_type", "mode_flag", "progress", "joint_limit_margin") else -1.0), "high": 1.0,
-                     "dtype": "float32"} for k, (_, n) in kcfg.OBS_LAYOUT.items()}
+    layout = kcfg.OBS_LAYOUT
+    if getattr(ppo, "obs_dim", kcfg.OBS_DIM) != kcfg.OBS_DIM:   # route wrappers with include_route_keys (route_observation.py:18-28)
+        from . import route_config as rcfg
+
+        layout = rcfg.ROUTE_OBS_LAYOUT
+    obs_space = {k: {"shape": [n], "low": (0.0 if k in ("task_type", "mode_flag", "progress", "joint_limit_margin", "route_scalar") else -1.0), "high": 1.0,
+                     "dtype": "float32"} for k, (_, n) in layout.items()}
     return {
         "policy_class": {":type:": "<class 'abc.ABCMeta'>", "__module__": "stable_baselines3.common.policies",
                          "__name__": "MultiInputActorCriticPolicy", ":serialized:": None},

@@ -29,7 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: arra
 
 namespace {
 
-constexpr int IN = KP1_MLP_IN, INP = KP1_MLP_IN_PAD, ACT = KP1_MLP_ACT, HEADS = 8;
+constexpr int ACT = KP1_MLP_ACT, HEADS = 8;  // observation width: ParamLayout::IN (56, or 80 with the route keys), padded to INP (64 / 128)
 constexpr float LOG_SQRT_2PI = 0.9189385332046727f;
 
 enum { EPI_BIAS_TANH = 0, EPI_DTANH = 1 };
@@ -648,13 +648,15 @@ __global__ void __launch_bounds__(256) head_train_kernel(const HeadArgs a) {
 
 // ---------------------------------------------------------------------------------------------- optimiser
 struct ParamLayout {  // offsets into the flat SB3-order vector
-  int H, Hp;
+  int H, Hp, IN, INP;  // INP: IN rounded up to the k depth the GEMMs are instantiated for (64 or 128)
   int64_t log_std, p_w1, p_b1, p_w2, p_b2, v_w1, v_b1, v_w2, v_b2, a_w, a_b, c_w, c_b, total;
 };
 
-__host__ __device__ inline ParamLayout make_layout(int H) {
+__host__ __device__ inline ParamLayout make_layout(int H, int IN = KP1_MLP_IN) {
   ParamLayout L;
   L.H = H;
+  L.IN = IN;
+  L.INP = IN <= 64 ? 64 : 128;
   L.Hp = (H + 127) / 128 * 128;
   int64_t o = 0;
   L.log_std = o; o += ACT;
@@ -693,7 +695,7 @@ __host__ __device__ inline int64_t frag_at(int64_t n, int64_t k, int64_t N) {
 
 // flat SB3 vector element i -> its place(s) in the kernel-format weights (zero padding pre-set once at creation)
 __device__ __forceinline__ void pack_one(int64_t i, float v, const ParamLayout& L, const Packed& k) {
-  const int H = L.H, Hp = L.Hp;
+  const int H = L.H, Hp = L.Hp, IN = L.IN, INP = L.INP;
   if (i < L.p_w1) {
     k.log_std[i] = v;
   } else if (i < L.p_b1) {
@@ -780,7 +782,7 @@ struct PartialSrc {
 
 __device__ __forceinline__ PartialSrc finalize_source(const FinalizeArgs& a, int64_t i) {
   const ParamLayout& L = a.L;
-  const int H = L.H, Hp = L.Hp;
+  const int H = L.H, Hp = L.Hp, IN = L.IN;
   PartialSrc r;
   r.add = 0.f;
   r.wide = true;
@@ -1061,23 +1063,32 @@ int launch_fused(const FusedArgs& fa_in, hipStream_t stream) {
   fa.n_cus = n_cus;
   fa.stagger_ticks = n_wgs > n_cus ? stagger_us * 100 : 0;   // only when CUs hold two workgroups at once
   const size_t bytes = sizeof(float) * FU_LDS_FLOATS;
-  HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  hipLaunchKernelGGL(mlp_tile_kernel<true>, dim3((fa.n + FU_BM - 1) / FU_BM, 1, 2), dim3(FU_NTH), bytes, stream, fa);
+  const dim3 grid((fa.n + FU_BM - 1) / FU_BM, 1, 2);
+  if (fa.inp == 64) {
+    HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL((mlp_tile_kernel<true, 2>), grid, dim3(FU_NTH), bytes, stream, fa);
+  } else {
+    HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL((mlp_tile_kernel<true, 4>), grid, dim3(FU_NTH), bytes, stream, fa);
+  }
   return KP1_OK;
 }
 
 int launch_fused_infer(const FusedArgs& fa, hipStream_t stream) {
   const size_t bytes = sizeof(float) * FU_LDS_FLOATS;
-  HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   // the value net is skipped when no value is asked for (deterministic evaluators), the policy net when only values are
   const bool want_pi = fa.mean || fa.action || fa.clipped || fa.log_prob;
   if (!want_pi && !fa.value) return KP1_OK;
   FusedArgs f = fa;
-  if (want_pi && fa.value) {
-    hipLaunchKernelGGL(mlp_tile_kernel<false>, dim3((fa.n + FU_BM - 1) / FU_BM, 1, 2), dim3(FU_NTH), bytes, stream, f);
+  const bool both = want_pi && fa.value;
+  if (!both) f.net_base = want_pi ? 0 : 1;
+  const dim3 grid((fa.n + FU_BM - 1) / FU_BM, 1, both ? 2 : 1);
+  if (fa.inp == 64) {
+    HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL((mlp_tile_kernel<false, 2>), grid, dim3(FU_NTH), bytes, stream, f);
   } else {
-    f.net_base = want_pi ? 0 : 1;
-    hipLaunchKernelGGL(mlp_tile_kernel<false>, dim3((fa.n + FU_BM - 1) / FU_BM, 1, 1), dim3(FU_NTH), bytes, stream, f);
+    HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL((mlp_tile_kernel<false, 4>), grid, dim3(FU_NTH), bytes, stream, f);
   }
   return KP1_OK;
 }
@@ -1092,7 +1103,7 @@ int launch_tn_frag(const TnFragArgs& t, hipStream_t stream) {
 
 // forward layers 1 and 2 for n rows (both nets): h1, h2 filled
 int launch_forward_layers(kp1_mlp* m, const float* obs, int obs_stride, const int64_t* idx, int n, hipStream_t stream) {
-  const int Hp = m->Hp;
+  const int Hp = m->Hp, IN = m->L.IN, INP = m->L.INP;
   const int64_t act_stride = (int64_t)m->max_batch * Hp;
   GemmNT g{};
   g.A = obs; g.lda = obs_stride; g.strideA = 0; g.gather = idx;
@@ -1141,9 +1152,14 @@ int launch_tn(kp1_mlp* m, GemmTN t, int n_o_tiles, int slab_cols, float* slab, i
 extern "C" {
 
 int64_t kp1_mlp_num_params(int32_t hidden) { return hidden > 0 ? make_layout(hidden).total : 0; }
+int64_t kp1_mlp_num_params_ex(int32_t hidden, int32_t obs_dim) { return hidden > 0 && obs_dim > 0 && obs_dim <= 128 ? make_layout(hidden, obs_dim).total : 0; }
 
-int kp1_mlp_create(int32_t device, int32_t hidden, int32_t max_batch, kp1_mlp** out) {
+int kp1_mlp_create(int32_t device, int32_t hidden, int32_t max_batch, kp1_mlp** out) { return kp1_mlp_create_ex(device, hidden, KP1_MLP_IN, max_batch, out); }
+
+int kp1_mlp_create_ex(int32_t device, int32_t hidden, int32_t obs_dim, int32_t max_batch, kp1_mlp** out) {
   if (!out || hidden <= 0 || hidden > 1024 || max_batch <= 0) return fail(KP1_ERR_INVALID, "bad argument to kp1_mlp_create");
+  if (obs_dim != KP1_MLP_IN && obs_dim != KP1_MLP_IN_ROUTE)
+    return fail(KP1_ERR_UNSUPPORTED, "obs_dim must be 56 (ArmKinematicEnv) or 80 (route observation keys)");
   if (hidden != 128 && hidden != 256)
     return fail(KP1_ERR_UNSUPPORTED, "hidden must be 128 or 256 (MFMA kernels are instantiated for these widths; 2x256 is BASELINE config 2)");
   int count = 0;
@@ -1153,10 +1169,10 @@ int kp1_mlp_create(int32_t device, int32_t hidden, int32_t max_batch, kp1_mlp** 
   kp1_mlp* m = new kp1_mlp();
   m->device = device;
   m->H = hidden;
-  m->L = make_layout(hidden);
+  m->L = make_layout(hidden, obs_dim);
   m->Hp = m->L.Hp;
   m->max_batch = (max_batch + 127) / 128 * 128;
-  const int64_t Hp = m->Hp, mb = m->max_batch;
+  const int64_t Hp = m->Hp, mb = m->max_batch, INP = m->L.INP;
   auto alloc = [&](void** p, size_t bytes) -> int {
     if (hipMalloc(p, bytes) != hipSuccess) return fail(KP1_ERR_ALLOC, "hipMalloc failed in kp1_mlp_create");
     m->allocs.push_back(*p);
@@ -1226,12 +1242,13 @@ int kp1_mlp_forward(kp1_mlp* m, const float* obs, int32_t obs_stride, int32_t n,
                     float* clipped_action, float* log_prob, void* stream) {
   if (!m || !obs) return fail(KP1_ERR_INVALID, "NULL argument");
   if (n <= 0 || n > m->max_batch) return fail(KP1_ERR_INVALID, "n exceeds the workspace max_batch");
-  if (obs_stride != IN && obs_stride != INP) return fail(KP1_ERR_INVALID, "obs_stride must be 56 or 64");
+  const int IN = m->L.IN, INP = m->L.INP;
+  if (obs_stride != IN && obs_stride != INP) return fail(KP1_ERR_INVALID, "obs_stride must be the observation width or its padded width (56 / 64, or 80 / 128)");
   int rc = mlp_check_device(m);
   if (rc != KP1_OK) return rc;
   if (m->fused && m->Hp == FU_HP) {
     FusedArgs fa{};
-    fa.obs = obs; fa.obs_stride = obs_stride; fa.Kreal = obs_stride >= INP ? INP : IN; fa.idx = nullptr; fa.n = n;
+    fa.obs = obs; fa.obs_stride = obs_stride; fa.Kreal = obs_stride >= INP ? INP : IN; fa.inp = INP; fa.idx = nullptr; fa.n = n;
     fa.k = m->k;
     fa.noise = noise; fa.mean = mean; fa.value = value; fa.action = action; fa.clipped = clipped_action; fa.log_prob = log_prob;
     rc = launch_fused_infer(fa, (hipStream_t)stream);
@@ -1256,7 +1273,8 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
                       float* stats_out, int32_t grad_is_zero, void* stream_) {
   if (!m || !obs || !actions || !old_log_prob || !advantages || !returns || !grad_out) return fail(KP1_ERR_INVALID, "NULL argument");
   if (n <= 0 || n > m->max_batch) return fail(KP1_ERR_INVALID, "n exceeds the workspace max_batch");
-  if (obs_stride != IN && obs_stride != INP) return fail(KP1_ERR_INVALID, "obs_stride must be 56 or 64");
+  const int IN = m->L.IN, INP = m->L.INP;
+  if (obs_stride != IN && obs_stride != INP) return fail(KP1_ERR_INVALID, "obs_stride must be the observation width or its padded width (56 / 64, or 80 / 128)");
   int rc = mlp_check_device(m);
   if (rc != KP1_OK) return rc;
   hipStream_t stream = (hipStream_t)stream_;
@@ -1273,7 +1291,7 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   const int hpart_stride = 10 * Hp + 32;
   if (fused) {
     FusedArgs fa{};
-    fa.obs = obs; fa.obs_stride = obs_stride; fa.Kreal = obs_stride >= INP ? INP : IN; fa.idx = idx; fa.n = n;
+    fa.obs = obs; fa.obs_stride = obs_stride; fa.Kreal = obs_stride >= INP ? INP : IN; fa.inp = INP; fa.idx = idx; fa.n = n;
     fa.k = m->k;
     fa.actions = actions; fa.old_logp = old_log_prob; fa.adv = advantages; fa.ret = returns;
     fa.adv_partials = m->partials; fa.n_adv_partials = N_PARTIALS; fa.adv_stats = adv_stats_dev; fa.adv_mean = adv_mean; fa.adv_inv_std = adv_inv_std;
@@ -1323,6 +1341,7 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   int s2_n = 0, s1_n = 0;
   if (fused) {
     TnFragArgs t{};
+    t.inp = INP;
     t.dz2 = m->dz2; t.h1 = m->h1; t.dz1 = m->dz1; t.act_stride = act_stride; t.xf = m->xf;
     t.slab2 = m->slab; t.s2_net = (int64_t)Hp * Hp; t.s2_chunk = 2 * t.s2_net;
     t.slab1 = m->slab1; t.s1_net = (int64_t)Hp * INP; t.s1_chunk = 2 * t.s1_net;
@@ -1378,7 +1397,7 @@ int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32
   int rc = mlp_check_device(m);
   if (rc != KP1_OK) return rc;
   hipStream_t stream = (hipStream_t)stream_;
-  const int Hp = m->Hp;
+  const int Hp = m->Hp, IN = m->L.IN, INP = m->L.INP;
   const int64_t act_stride = (int64_t)m->max_batch * Hp;
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
@@ -1412,7 +1431,7 @@ int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32
       } else if (which == 4) {
         // the fused tile kernel on this workspace: rows 0..n of obs, loss inputs = finite scratch values (layer-2 activations)
         FusedArgs fa{};
-        fa.obs = obs; fa.obs_stride = obs_stride; fa.Kreal = obs_stride >= INP ? INP : IN; fa.idx = nullptr; fa.n = n;
+        fa.obs = obs; fa.obs_stride = obs_stride; fa.Kreal = obs_stride >= INP ? INP : IN; fa.inp = INP; fa.idx = nullptr; fa.n = n;
         fa.k = m->k;
         fa.actions = m->h2; fa.old_logp = m->h2 + (int64_t)ACT * n; fa.adv = m->h2 + (int64_t)(ACT + 1) * n; fa.ret = m->h2 + (int64_t)(ACT + 2) * n;
         fa.adv_mode = 3; fa.adv_mean = 0.f; fa.adv_inv_std = 1.f;
@@ -1422,6 +1441,7 @@ int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32
         if (launch_fused(fa, stream) != KP1_OK) return KP1_ERR_NO_DEVICE;
       } else {
         TnFragArgs t{};
+    t.inp = INP;
         t.dz2 = m->dz2; t.h1 = m->h1; t.dz1 = m->dz1; t.act_stride = act_stride; t.xf = m->xf;
         t.slab2 = m->slab; t.s2_net = (int64_t)Hp * Hp; t.s2_chunk = 2 * t.s2_net;
         t.slab1 = m->slab1; t.s1_net = (int64_t)Hp * INP; t.s1_chunk = 2 * t.s1_net;

@@ -15,14 +15,14 @@ def _p(t: torch.Tensor | None):
 
 
 class MlpKernels:
-    def __init__(self, hidden: int, device: torch.device, max_batch: int = 8192) -> None:
+    def __init__(self, hidden: int, device: torch.device, max_batch: int = 8192, obs_dim: int = OBS_DIM) -> None:
         self.L = native.load()
         L = self.L
         vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
-        L.kp1_mlp_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+        L.kp1_mlp_create_ex.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
         L.kp1_mlp_destroy.argtypes = [vp]
-        L.kp1_mlp_num_params.argtypes = [i32]
-        L.kp1_mlp_num_params.restype = C.c_int64
+        L.kp1_mlp_num_params_ex.argtypes = [i32, i32]
+        L.kp1_mlp_num_params_ex.restype = C.c_int64
         L.kp1_mlp_pack_weights.argtypes = [vp, vp, vp]
         L.kp1_mlp_forward.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.kp1_mlp_loss_grad.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, f32, f32, vp, f32, f32, f32, f32, vp, vp, i32, vp]
@@ -33,8 +33,10 @@ class MlpKernels:
         self.device = device
         self.max_batch = int(max_batch)
         self._h = vp()
-        native.check(L.kp1_mlp_create(device.index or 0, hidden, self.max_batch, C.byref(self._h)))
-        self.num_params = int(L.kp1_mlp_num_params(hidden))
+        self.obs_dim = int(obs_dim)                      # 56, or 80 with the route observation keys
+        self.obs_pad = 64 if self.obs_dim <= 64 else 128   # row pitch the kernels also accept (zero padded)
+        native.check(L.kp1_mlp_create_ex(device.index or 0, hidden, self.obs_dim, self.max_batch, C.byref(self._h)))
+        self.num_params = int(L.kp1_mlp_num_params_ex(hidden, self.obs_dim))
 
     def close(self) -> None:
         if self._h.value:
@@ -55,7 +57,7 @@ class MlpKernels:
         native.check(self.L.kp1_mlp_pack_weights(self._h, _p(flat_params), self._stream()))
 
     def forward(self, obs: torch.Tensor, *, noise=None, mean=None, value=None, action=None, clipped=None, log_prob=None) -> None:
-        """obs [n, 56|64] contiguous f32; outputs written in place (None = skip)."""
+        """obs [n, obs_dim | obs_pad] contiguous f32; outputs written in place (None = skip)."""
         n, stride = obs.shape[0], obs.shape[1]
         assert obs.is_contiguous() and obs.dtype == torch.float32
         native.check(self.L.kp1_mlp_forward(self._h, _p(obs), stride, n, _p(noise), _p(mean), _p(value), _p(action), _p(clipped), _p(log_prob), self._stream()))

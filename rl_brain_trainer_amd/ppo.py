@@ -69,14 +69,15 @@ class PPOConfig:
         return cls(**data)
 
 
-def param_spec(hidden: int) -> list[tuple[str, tuple[int, ...]]]:
-    """SB3 MultiInputActorCriticPolicy.state_dict() keys/shapes for net_arch pi=vf=[hidden, hidden]."""
+def param_spec(hidden: int, obs_dim: int = OBS_DIM) -> list[tuple[str, tuple[int, ...]]]:
+    """SB3 MultiInputActorCriticPolicy.state_dict() keys/shapes for net_arch pi=vf=[hidden, hidden]; ``obs_dim`` = width of the
+    flattened Dict observation (56, or 80 with the route keys of route/route_observation.py:14-61)."""
     H = hidden
     return [
         ("log_std", (ACT_DIM,)),
-        ("mlp_extractor.policy_net.0.weight", (H, OBS_DIM)), ("mlp_extractor.policy_net.0.bias", (H,)),
+        ("mlp_extractor.policy_net.0.weight", (H, obs_dim)), ("mlp_extractor.policy_net.0.bias", (H,)),
         ("mlp_extractor.policy_net.2.weight", (H, H)), ("mlp_extractor.policy_net.2.bias", (H,)),
-        ("mlp_extractor.value_net.0.weight", (H, OBS_DIM)), ("mlp_extractor.value_net.0.bias", (H,)),
+        ("mlp_extractor.value_net.0.weight", (H, obs_dim)), ("mlp_extractor.value_net.0.bias", (H,)),
         ("mlp_extractor.value_net.2.weight", (H, H)), ("mlp_extractor.value_net.2.bias", (H,)),
         ("action_net.weight", (ACT_DIM, H)), ("action_net.bias", (ACT_DIM,)),
         ("value_net.weight", (1, H)), ("value_net.bias", (1,)),
@@ -86,10 +87,11 @@ def param_spec(hidden: int) -> list[tuple[str, tuple[int, ...]]]:
 class ActorCritic:
     """Flat fp32 parameter buffer with SB3-named views."""
 
-    def __init__(self, hidden: int, device: torch.device, seed: int = 0) -> None:
+    def __init__(self, hidden: int, device: torch.device, seed: int = 0, obs_dim: int = OBS_DIM) -> None:
         self.hidden = hidden
+        self.obs_dim = int(obs_dim)
         self.device = device
-        self.spec = param_spec(hidden)
+        self.spec = param_spec(hidden, self.obs_dim)
         self.numel = sum(math.prod(s) for _, s in self.spec)
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
         self.views: dict[str, torch.Tensor] = {}
@@ -180,7 +182,8 @@ class PPO:
         self.backend = backend
         self.L = native.load()
         self.n_envs = env.n_envs
-        self.policy = ActorCritic(cfg.hidden, self.device, seed=cfg.seed)
+        self.obs_dim = int(getattr(env, "obs_dim", OBS_DIM))   # 80 for the route envs with include_route_keys
+        self.policy = ActorCritic(cfg.hidden, self.device, seed=cfg.seed, obs_dim=self.obs_dim)
         self.dist.broadcast(self.policy.flat)
         self.adam_m = torch.zeros_like(self.policy.flat)
         self.adam_v = torch.zeros_like(self.policy.flat)
@@ -190,10 +193,10 @@ class PPO:
             curriculum.attach(env)
         T, N = cfg.n_steps, self.n_envs
         dev = self.device
-        # hip backend: observation rows are written with pitch 64 (zero padded) so the MFMA GEMMs read them directly
-        self.obs_w = 64 if backend == "hip" else OBS_DIM
+        # hip backend: observation rows are written with pitch 64 / 128 (zero padded) so the MFMA GEMMs read them directly
+        self.obs_w = (64 if self.obs_dim <= 64 else 128) if backend == "hip" else self.obs_dim
         if backend == "hip":
-            env.set_obs_stride(64)
+            env.set_obs_stride(self.obs_w)
         self.obs_buf = torch.zeros((T + 1, N, self.obs_w), dtype=torch.float32, device=dev)
         self.term_obs_buf = torch.zeros((T, N, self.obs_w), dtype=torch.float32, device=dev)
         self.act_buf = torch.zeros((T, N, ACT_DIM), dtype=torch.float32, device=dev)
@@ -215,7 +218,7 @@ class PPO:
             from . import mlp as _mlp
 
             local_bs = max(cfg.batch_size // self.dist.world_size, 1)
-            self._mlp = _mlp.MlpKernels(cfg.hidden, self.device, max_batch=max(N, local_bs, 8192))
+            self._mlp = _mlp.MlpKernels(cfg.hidden, self.device, max_batch=max(N, local_bs, 8192), obs_dim=self.obs_dim)
             self._mlp.pack(self.policy.flat)
             self.grad = torch.zeros_like(self.policy.flat)
             self.stats_dev = torch.zeros(4, dtype=torch.float32, device=dev)
@@ -238,7 +241,7 @@ class PPO:
         """mean[n,7], value[n] for obs [n, 56 or 64]"""
         if self._mlp is not None:
             return self._mlp.mean_value(obs.contiguous())
-        return mlp_forward(self.policy.views, obs[:, :OBS_DIM])
+        return mlp_forward(self.policy.views, obs[:, :self.obs_dim])
 
     def predict(self, obs: torch.Tensor, deterministic: bool = True) -> torch.Tensor:
         """model.predict(obs, deterministic): mean (or a sample) clipped to the action space (eval_three_stage.py:25-27)."""
@@ -479,7 +482,7 @@ class PPO:
     def _minibatch_step(self, obs, act, old_logp, adv, ret) -> torch.Tensor:
         cfg = self.cfg
         adv = self._normalize_adv(adv)
-        grad, terms = self._torch_loss_and_grad(obs[:, :OBS_DIM], act, old_logp, adv, ret)
+        grad, terms = self._torch_loss_and_grad(obs[:, :self.obs_dim], act, old_logp, adv, ret)
         self.dist.all_reduce_sum(grad)
         self._clip_and_adam(grad)
         return terms
@@ -546,14 +549,15 @@ class InferencePolicy:
 
     def __init__(self, state_dict: dict[str, torch.Tensor], device: torch.device | int = 0, max_batch: int = 8192) -> None:
         self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
-        hidden = int(state_dict["mlp_extractor.policy_net.0.weight"].shape[0])
-        self.policy = ActorCritic(hidden, self.device)
+        hidden, obs_dim = (int(v) for v in state_dict["mlp_extractor.policy_net.0.weight"].shape)
+        self.obs_dim = obs_dim
+        self.policy = ActorCritic(hidden, self.device, obs_dim=obs_dim)
         self.policy.load_state_dict(state_dict)
         self._mlp = None
         if hidden in (128, 256):
             from . import mlp as _mlp
 
-            self._mlp = _mlp.MlpKernels(hidden, self.device, max_batch=max_batch)
+            self._mlp = _mlp.MlpKernels(hidden, self.device, max_batch=max_batch, obs_dim=obs_dim)
             self._mlp.pack(self.policy.flat)
 
     @classmethod
@@ -569,7 +573,7 @@ class InferencePolicy:
         if self._mlp is not None:
             mean, _ = self._mlp.mean_value(obs.contiguous())
         else:
-            mean, _ = mlp_forward(self.policy.views, obs[:, :OBS_DIM].contiguous())
+            mean, _ = mlp_forward(self.policy.views, obs[:, :self.obs_dim].contiguous())
         return mean.clamp(-1.0, 1.0)
 
     __call__ = predict

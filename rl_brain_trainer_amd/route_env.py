@@ -42,6 +42,7 @@ def _bind(L) -> None:
     L.kp1_route_set_window.argtypes = [vp, i32, i32]
     L.kp1_route_seed.argtypes = [vp, u64, u64]
     L.kp1_route_obs_dim.argtypes = [vp]
+    L.kp1_route_set_obs_stride.argtypes = [vp, C.c_int32]
     L.kp1_route_reset.argtypes = [vp, vp, C.POINTER(_RouteResetOpts), vp]
     L.kp1_route_step.argtypes = [vp, vp, vp, vp, vp, vp, i32]
     L.kp1_route_get_info.argtypes = [vp, C.POINTER(_RouteInfoView)]
@@ -78,6 +79,7 @@ class RouteVecEnv:
             native.check(self.L.kp1_route_create(self.base._handle, C.byref(route_cfg), C.c_void_p(self.route_q.ctypes.data), self.n_waypoints, int(seed),
                                                  int(first_env_id), C.byref(self._handle)))
         self.obs_dim = int(self.L.kp1_route_obs_dim(self._handle))
+        self.obs_stride = self.obs_dim
         n = self.n_envs
         self.obs = torch.zeros((n, self.obs_dim), dtype=torch.float32, device=self.device)
         self.terminal_obs = torch.zeros_like(self.obs)
@@ -153,6 +155,20 @@ class RouteVecEnv:
                                             C.c_void_p(self.obs.data_ptr())))
         return self.obs
 
+    def set_obs_stride(self, stride: int) -> None:
+        """Row pitch of every observation buffer handed to reset / step (obs_dim, or the MFMA kernels' padded 64 / 128)."""
+        native.check(self.L.kp1_route_set_obs_stride(self._handle, int(stride)))
+        self.obs_stride = int(stride)
+        self.obs = torch.zeros((self.n_envs, self.obs_stride), dtype=torch.float32, device=self.device)
+        self.terminal_obs = torch.zeros_like(self.obs)
+
+    def step_into(self, actions: torch.Tensor, obs: torch.Tensor, reward: torch.Tensor, done: torch.Tensor, terminal_obs: torch.Tensor | None,
+                  auto_reset: bool = True) -> None:
+        """Zero-copy variant used by the PPO rollout loop (ArmKinematicVecEnv.step_into): outputs go into caller-owned buffers."""
+        native.check(self.L.kp1_route_step(self._handle, C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()), C.c_void_p(reward.data_ptr()),
+                                           C.c_void_p(done.data_ptr()), C.c_void_p(terminal_obs.data_ptr()) if terminal_obs is not None else None,
+                                           int(auto_reset)))
+
     def step(self, actions: torch.Tensor, *, auto_reset: bool = True) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """actions [N, 7] in the env's real type; returns (obs [N, obs_dim], reward [N], done bits [N] uint8)."""
         if actions.shape != (self.n_envs, kcfg.NJ):
@@ -164,7 +180,7 @@ class RouteVecEnv:
 
     @staticmethod
     def obs_dict(obs: torch.Tensor) -> dict[str, torch.Tensor]:
-        layout = rcfg.ROUTE_OBS_LAYOUT if obs.shape[-1] == rcfg.ROUTE_OBS_DIM else kcfg.OBS_LAYOUT
+        layout = rcfg.ROUTE_OBS_LAYOUT if obs.shape[-1] in (rcfg.ROUTE_OBS_DIM, 128) else kcfg.OBS_LAYOUT   # 128 / 64: padded PPO rows
         return {k: obs[..., o:o + w] for k, (o, w) in layout.items()}
 
     def info(self) -> dict[str, torch.Tensor]:

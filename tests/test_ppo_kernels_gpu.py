@@ -19,8 +19,8 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
 
 
-def _policy(hidden=256, seed=3, scale_heads=True):
-    pol = P.ActorCritic(hidden, DEV, seed=seed)
+def _policy(hidden=256, seed=3, scale_heads=True, obs_dim=56):
+    pol = P.ActorCritic(hidden, DEV, seed=seed, obs_dim=obs_dim)
     g = torch.Generator(device="cpu").manual_seed(seed + 1)
     # non-trivial biases / log_std so every gradient path is exercised
     for name, _ in pol.spec:
@@ -32,17 +32,19 @@ def _policy(hidden=256, seed=3, scale_heads=True):
     return pol
 
 
-def test_fused_tile_kernel_matches_layerwise_kernels_and_is_reproducible():
+@pytest.mark.parametrize("obs_dim", [56, 80])
+def test_fused_tile_kernel_matches_layerwise_kernels_and_is_reproducible(obs_dim):
     """Same minibatch through mlp_train_tile_kernel and through gemm_nt x3 + head_train: the GEMM k-order is identical, only
     the per-tile partial sums differ in grouping (32- vs 64-row tiles), so gradients agree to a few fp32 ulps of their scale;
     two runs of the fused path are bitwise equal (no float atomics)."""
-    pol = _policy(scale_heads=False)
-    k = MlpKernels(256, DEV, max_batch=8192)
+    D, W = obs_dim, (64 if obs_dim <= 64 else 128)
+    pol = _policy(scale_heads=False, obs_dim=D)
+    k = MlpKernels(256, DEV, max_batch=8192, obs_dim=D)
     k.pack(pol.flat)
     g = torch.Generator(device=DEV).manual_seed(5)
     total, n = 30000, 8000          # ragged last tile (8000 = 250 * 32) and a gather
-    obs = torch.zeros((total, 64), device=DEV)
-    obs[:, :56] = torch.rand((total, 56), device=DEV, generator=g) * 2 - 1
+    obs = torch.zeros((total, W), device=DEV)
+    obs[:, :D] = torch.rand((total, D), device=DEV, generator=g) * 2 - 1
     act = torch.randn((total, 7), device=DEV, generator=g) * 0.5
     old_logp = -7.0 + 0.3 * torch.randn(total, device=DEV, generator=g)
     adv = torch.randn(total, device=DEV, generator=g)
@@ -70,16 +72,17 @@ def test_fused_tile_kernel_matches_layerwise_kernels_and_is_reproducible():
 
 
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("n,stride", [(4096, 56), (4096, 64), (100, 56), (8192, 64), (12000, 64), (1, 64)])
+@pytest.mark.parametrize("n,stride", [(4096, 56), (4096, 64), (100, 56), (8192, 64), (12000, 64), (1, 64),
+                                      (4096, 80), (8192, 128), (100, 80), (1, 128)])   # 80 / 128: route observation (80 floats, pitch 128)
 def test_mlp_forward_vs_torch(n, stride, fused):
-    pol = _policy()
-    k = MlpKernels(256, DEV, max_batch=16384)
+    D = 56 if stride <= 64 else 80
+    pol = _policy(obs_dim=D)
+    k = MlpKernels(256, DEV, max_batch=16384, obs_dim=D)
     k.set_fused(fused)
     k.pack(pol.flat)
     g = torch.Generator(device=DEV).manual_seed(0)
     obs = torch.rand((n, stride), device=DEV, generator=g) * 2 - 1
-    if stride == 64:
-        obs[:, 56:] = 0
+    obs[:, D:] = 0
     noise = torch.randn((n, 7), device=DEV, generator=g)
     mean = torch.empty((n, 7), device=DEV)
     value = torch.empty(n, device=DEV)
@@ -87,7 +90,7 @@ def test_mlp_forward_vs_torch(n, stride, fused):
     clipped = torch.empty((n, 7), device=DEV)
     logp = torch.empty(n, device=DEV)
     k.forward(obs, noise=noise, mean=mean, value=value, action=action, clipped=clipped, log_prob=logp)
-    ref_mean, ref_value = P.mlp_forward(pol.views, obs[:, :56].contiguous())
+    ref_mean, ref_value = P.mlp_forward(pol.views, obs[:, :D].contiguous())
     assert torch.allclose(mean, ref_mean, rtol=1e-4, atol=2e-5), (mean - ref_mean).abs().max()
     assert torch.allclose(value, ref_value, rtol=1e-4, atol=2e-5), (value - ref_value).abs().max()
     ref_action = ref_mean + torch.exp(pol.views["log_std"]) * noise
@@ -106,17 +109,19 @@ def test_mlp_forward_vs_torch(n, stride, fused):
 
 
 @pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("obs_dim", [56, 80])
 @pytest.mark.parametrize("n,total,gather", [(8192, 20000, True), (4096, 4096, False), (1000, 5000, True), (16384, 40000, True), (33, 64, True)])
-def test_mlp_loss_grad_vs_torch_autograd(n, total, gather, fused):
-    pol = _policy(scale_heads=False)
-    k = MlpKernels(256, DEV, max_batch=16384)
+def test_mlp_loss_grad_vs_torch_autograd(n, total, gather, fused, obs_dim):
+    D, W = obs_dim, (64 if obs_dim <= 64 else 128)
+    pol = _policy(scale_heads=False, obs_dim=D)
+    k = MlpKernels(256, DEV, max_batch=16384, obs_dim=D)
     k.set_fused(fused)
     k.pack(pol.flat)
     g = torch.Generator(device=DEV).manual_seed(1)
-    obs = torch.zeros((total, 64), device=DEV)
-    obs[:, :56] = torch.rand((total, 56), device=DEV, generator=g) * 2 - 1
+    obs = torch.zeros((total, W), device=DEV)
+    obs[:, :D] = torch.rand((total, D), device=DEV, generator=g) * 2 - 1
     with torch.no_grad():
-        m0, v0 = P.mlp_forward(pol.views, obs[:, :56].contiguous())
+        m0, v0 = P.mlp_forward(pol.views, obs[:, :D].contiguous())
     act = m0 + torch.exp(pol.views["log_std"]) * torch.randn((total, 7), device=DEV, generator=g)
     # old log-probs from a slightly different policy so ratios spread around 1 and both clip branches occur
     old_logp = P.gaussian_log_prob(act, m0 + 0.05 * torch.randn((total, 7), device=DEV, generator=g), pol.views["log_std"])
@@ -136,7 +141,7 @@ def test_mlp_loss_grad_vs_torch_autograd(n, total, gather, fused):
         cnt = math.prod(shape)
         Pv[name] = flat[off:off + cnt].view(shape)
         off += cnt
-    mean, value = P.mlp_forward(Pv, obs[sel, :56])
+    mean, value = P.mlp_forward(Pv, obs[sel, :D])
     logp = P.gaussian_log_prob(act[sel], mean, Pv["log_std"])
     a = adv[sel]
     a = (a - a.mean()) / (a.std() + 1e-8)
