@@ -123,6 +123,11 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
  * (mlp_tile_kernel<false>) instead of three; 0 selects the layer-wise kernels (always used for hidden = 128).  Same results up
  * to fp32 summation order of the per-tile partials. */
 #define KP1_MLP_OPT_FUSED 1
+/* KP1_MLP_OPT_ACTOR_EXTRA_STEPS (default 0): optimiser steps the actor tensors (mlp_extractor.policy_net.*, action_net.*) have taken
+ * on top of the common count -- torch.optim.Adam counts per tensor, and the route trainer's teacher-anchor callback
+ * (route/teacher_anchor.py:68-87) steps only the tensors its imitation loss reaches.  kp1_mlp_adam_step uses common + extra in
+ * the bias corrections of those tensors. */
+#define KP1_MLP_OPT_ACTOR_EXTRA_STEPS 2
 int kp1_mlp_set_option(kp1_mlp* m, int32_t option, int32_t value);
 
 /* clip_grad_norm_(max_norm) + Adam(beta 0.9/0.999, eps) step on the flat vectors; the same pass repacks the kernel-format

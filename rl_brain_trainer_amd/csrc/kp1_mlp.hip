@@ -934,12 +934,13 @@ __global__ void __launch_bounds__(256) sumsq_partials_kernel(const float* __rest
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, const double* __restrict__ partials, int n_partials, float lr, float eps, float max_norm,
                                                    float bc1, float bc2_sqrt, const ParamLayout L, const Packed k, int zero_grad,
-                                                   const int* __restrict__ step_counter) {
+                                                   const int* __restrict__ step_counter, int host_step, const int* __restrict__ actor_extra) {
   __shared__ float scale_s;
+  float base_step = (float)host_step;
   if (step_counter) {  // bias corrections from the device-resident step count
-    const float st = (float)*step_counter;
-    bc1 = 1.f - powf(0.9f, st);
-    bc2_sqrt = sqrtf(1.f - powf(0.999f, st));
+    base_step = (float)*step_counter;
+    bc1 = 1.f - powf(0.9f, base_step);
+    bc2_sqrt = sqrtf(1.f - powf(0.999f, base_step));
   }
   double s = 0.0;
   if (threadIdx.x < 64) {
@@ -953,6 +954,14 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float*
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  // torch.optim.Adam keeps one step count per tensor: the actor tensors (policy_net.*, action_net.*) have taken *actor_extra
+  // more steps than the rest when a teacher-anchor side loss updates them between rollouts (route/teacher_anchor.py:68-87)
+  const int extra = *actor_extra;
+  if (extra != 0 && ((i >= L.p_w1 && i < L.v_w1) || (i >= L.a_w && i < L.c_w))) {
+    const float st = base_step + (float)extra;
+    bc1 = 1.f - powf(0.9f, st);
+    bc2_sqrt = sqrtf(1.f - powf(0.999f, st));
+  }
   const float gi = g[i] * scale_s;
   const float mi = 0.9f * m[i] + 0.1f * gi;
   const float vi = 0.999f * v[i] + 0.001f * gi * gi;
@@ -1224,6 +1233,12 @@ int kp1_mlp_set_option(kp1_mlp* m, int32_t option, int32_t value) {
   if (!m) return fail(KP1_ERR_INVALID, "NULL argument");
   if (option == KP1_MLP_OPT_FUSED) {
     m->fused = value ? 1 : 0;
+    return KP1_OK;
+  }
+  if (option == KP1_MLP_OPT_ACTOR_EXTRA_STEPS) {
+    if (value < 0) return fail(KP1_ERR_INVALID, "actor extra steps must be >= 0");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemcpy(m->step_dev + 1, &value, sizeof(int), hipMemcpyHostToDevice));
     return KP1_OK;
   }
   return fail(KP1_ERR_INVALID, "unknown kp1_mlp option");
@@ -1518,7 +1533,7 @@ int kp1_mlp_adam_step(kp1_mlp* m, float* params, float* grad, float* exp_avg, fl
   const float bc2 = 1.f - std::pow(0.999f, (float)host_step);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, params, grad, exp_avg, exp_avg_sq, n,
                      norm_partials, n_norm_partials, lr, eps, max_grad_norm, bc1, std::sqrt(bc2), m->L, m->k, zero_grad,
-                     step > 0 ? (const int*)nullptr : (const int*)m->step_dev);
+                     step > 0 ? (const int*)nullptr : (const int*)m->step_dev, host_step, (const int*)m->step_dev + 1);
   HIP_TRY(hipGetLastError());
   return KP1_OK;
 }

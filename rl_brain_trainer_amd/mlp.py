@@ -49,6 +49,12 @@ class MlpKernels:
         """hidden = 256: whole activation chain of a 32-row tile in one workgroup (default) vs the layer-wise kernels."""
         native.check(self.L.kp1_mlp_set_option(self._h, self.OPT_FUSED, int(bool(on))))
 
+    OPT_ACTOR_EXTRA_STEPS = 2
+
+    def set_actor_extra_steps(self, steps: int) -> None:
+        """Adam steps the actor tensors have taken beyond the common count (teacher-anchor side updates, teacher_anchor.py)."""
+        native.check(self.L.kp1_mlp_set_option(self._h, self.OPT_ACTOR_EXTRA_STEPS, int(steps)))
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 

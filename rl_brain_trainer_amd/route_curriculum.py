@@ -120,6 +120,13 @@ class RoutePrefixCurriculum:
         return self.on_step((done & 3) != 0, (done & 4) != 0, info["route_ready"].cpu().numpy(), info["route_orientation_hit"].cpu().numpy(),
                             info["route_regression"].cpu().numpy())
 
+    def observe_step(self, env: RouteVecEnv, done_bits: torch.Tensor) -> bool:
+        """PPO.step_callback form: ``done_bits`` = the rollout buffer row of this step (step_into does not fill env.done)."""
+        done = done_bits.cpu().numpy()
+        info = env.info()
+        return self.on_step((done & 3) != 0, (done & 4) != 0, info["route_ready"].cpu().numpy(), info["route_orientation_hit"].cpu().numpy(),
+                            info["route_regression"].cpu().numpy())
+
     def summary(self) -> dict[str, object]:
         stage = self.stages[self.current_stage_index]
         return {"stage_index": int(self.current_stage_index), "stage_name": stage.name, "prefix_end_index": int(stage.prefix_end_index),
@@ -260,3 +267,50 @@ def evaluate_sequential_route(*, policy: PolicyFn | Callable[[RouteVecEnv], Poli
         (root / "route_failure_report.json").write_text(json.dumps({"first_failure_index": summary["first_failure_index"],
                                                                     "first_failure_reason": summary["first_failure_reason"], "first_failure": failure}, indent=2))
     return {**summary, "rows": rows, "chunk_metrics": chunk_metrics(rows), "final_q": np.asarray(cq).tolist()}
+
+
+# --------------------------------------------------------------------------------------------- sequential gate
+def _passes_prefix120(summary: dict[str, Any], *, min_success_rate: float) -> bool:
+    return int(summary.get("longest_success_prefix", 0)) >= 120 and float(summary.get("success_rate", 0.0)) >= min_success_rate
+
+
+def evaluate_route_gate(*, evaluate: Callable[..., dict[str, Any]], artifact_root: str | Path, prefixes: Sequence[int], full_end_index: int | None,
+                        min_prefix120_success_rate: float, best_full_longest_prefix: int, full_prefix_tolerance: int, checkpoint: str = "",
+                        config: str = "", route_path: str = "") -> dict[str, Any]:
+    """eval/eval_route_gate.py:17-99.  ``evaluate(artifact_root=, start_index=, end_index=)`` runs one sequential evaluation (the trainer
+    binds evaluate_sequential_route to the policy under test); the accept / reject rules and the summary file are the reference's."""
+    root = Path(artifact_root)
+    root.mkdir(parents=True, exist_ok=True)
+    prefix_results: dict[str, Any] = {}
+    for prefix in prefixes:
+        prefix_results[f"prefix_{prefix}"] = evaluate(artifact_root=root / f"prefix_{prefix}", start_index=1, end_index=int(prefix))
+    full_summary = None
+    if full_end_index is not None:
+        full_summary = evaluate(artifact_root=root / f"full_{full_end_index}", start_index=1, end_index=int(full_end_index))
+    p120 = prefix_results.get("prefix_120")
+    p180 = prefix_results.get("prefix_180")
+    prefix120_retained = bool(p120 and _passes_prefix120(p120, min_success_rate=min_prefix120_success_rate))
+    expands_beyond_120 = bool(p180 and int(p180.get("longest_success_prefix", 0)) > 120)
+    first_failure_not_before_120 = bool(p180 and (p180.get("first_failure_index") is None or int(p180.get("first_failure_index", 0)) > 120))
+    full_not_too_regressed = True
+    if full_summary is not None:
+        full_not_too_regressed = int(full_summary.get("longest_success_prefix", 0)) >= int(best_full_longest_prefix - full_prefix_tolerance)
+    accepted = bool(prefix120_retained and expands_beyond_120 and first_failure_not_before_120 and full_not_too_regressed)
+    reasons: list[str] = []
+    if not prefix120_retained:
+        reasons.append("prefix120_retention_failed")
+    if not expands_beyond_120:
+        reasons.append("prefix180_did_not_expand_beyond_120")
+    if not first_failure_not_before_120:
+        reasons.append("prefix180_failed_before_or_at_120")
+    if not full_not_too_regressed:
+        reasons.append("full_route_prefix_regressed_too_much")
+    summary = {
+        "schema_version": "v5.route_gate.v1", "checkpoint": str(checkpoint), "config": str(config), "route_path": str(route_path), "accepted": accepted,
+        "rejection_reasons": reasons,
+        "criteria": {"min_prefix120_success_rate": float(min_prefix120_success_rate), "best_full_longest_prefix": int(best_full_longest_prefix),
+                     "full_prefix_tolerance": int(full_prefix_tolerance)},
+        "prefix_results": prefix_results, "full_result": full_summary,
+    }
+    (root / "route_gate_summary.json").write_text(json.dumps(summary, indent=2))
+    return summary

@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import json
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -93,3 +94,49 @@ def test_sequential_route_evaluator_matches_reference(tmp_path, gold):
         assert json.loads(json.dumps(out["chunk_metrics"])).keys() == case["chunk_metrics"].keys()
         assert np.max(np.abs(np.array(out["final_q"]) - np.array(case["final_q"]))) <= 1e-12
         assert (tmp_path / f"g{gain}" / "route_eval_sequential_summary.json").exists()
+
+
+def test_route_gate_matches_reference_decisions(tmp_path):
+    """eval_route_gate.evaluate_route_gate's accept / reject rules on 60 scripted sets of per-prefix summaries (the fixture was
+    produced by the reference's own function with its evaluator replaced by the same scripted summaries)."""
+    from rl_brain_trainer_amd.route_curriculum import evaluate_route_gate
+
+    cases = json.loads((GOLDEN / "route_gate.json").read_text())["cases"]
+    assert sum(c["accepted"] for c in cases) > 10 and sum(not c["accepted"] for c in cases) > 10
+    for n, case in enumerate(cases):
+        calls = []
+
+        def evaluate(*, artifact_root, start_index, end_index, case=case, calls=calls):
+            calls.append({"artifact_dir": Path(artifact_root).name, "start_index": int(start_index), "end_index": int(end_index)})
+            return dict(case["summaries"][str(int(end_index))])
+
+        out = evaluate_route_gate(evaluate=evaluate, artifact_root=tmp_path / f"g{n}", prefixes=case["prefixes"], full_end_index=case["full_end_index"],
+                                  **case["criteria"])
+        assert calls == case["calls"]
+        assert out["accepted"] == case["accepted"] and out["rejection_reasons"] == case["rejection_reasons"], n
+        assert out["schema_version"] == case["schema_version"] and sorted(out.keys()) == case["result_keys"]
+        assert json.loads((tmp_path / f"g{n}" / "route_gate_summary.json").read_text())["accepted"] == case["accepted"]
+
+
+def test_teacher_anchor_batch_order_and_flatten():
+    """The anchor batches are default_rng(0).integers(0, M, size=B) draws in call order (teacher_anchor.py:41, 62-69) and the Dict
+    observation is flattened in sorted-key order (SB3 CombinedExtractor) -- both host-only."""
+    from rl_brain_trainer_amd import route_config as rc
+    from rl_brain_trainer_amd.teacher_anchor import RouteTeacherAnchor, TeacherAnchorConfig, flatten_observation
+
+    a = RouteTeacherAnchor(TeacherAnchorConfig(enabled=True, dataset_path="x.npz", batch_size=7))
+    import torch
+
+    a._actions = torch.zeros((50, 7))
+    ref = np.random.default_rng(0)
+    for _ in range(5):
+        assert np.array_equal(a.sample_indices(), ref.integers(0, 50, size=7))
+    rng = np.random.default_rng(3)
+    obs = {k: rng.random((4, w)).astype(np.float32) for k, (_, w) in rc.ROUTE_OBS_LAYOUT.items()}
+    flat = flatten_observation(obs, rc.ROUTE_OBS_DIM)
+    assert flat.shape == (4, 80)
+    assert np.array_equal(flat, np.concatenate([obs[k] for k in sorted(obs)], axis=1))
+    with pytest.raises(ValueError):
+        flatten_observation({k: v for k, v in obs.items() if k != "route_tangent"}, rc.ROUTE_OBS_DIM)
+    with pytest.raises(ValueError):
+        RouteTeacherAnchor(TeacherAnchorConfig(enabled=True))
