@@ -155,6 +155,10 @@ class RouteVecEnv:
                                             C.c_void_p(self.obs.data_ptr())))
         return self.obs
 
+    def use_current_stream(self) -> None:
+        """Order this handle's launches on torch's current stream (the wrapper kernels run on the base handle's stream)."""
+        self.base.use_current_stream()
+
     def set_obs_stride(self, stride: int) -> None:
         """Row pitch of every observation buffer handed to reset / step (obs_dim, or the MFMA kernels' padded 64 / 128)."""
         native.check(self.L.kp1_route_set_obs_stride(self._handle, int(stride)))

@@ -37,7 +37,10 @@ def _make(n_envs=128, use_graphs=False, **kw):
 def test_route_ppo_rollout_and_gradient(use_graphs):
     env, ppo, _ = _make(use_graphs=use_graphs)
     assert env.obs_dim == 80 and ppo.obs_dim == 80 and ppo.obs_w == 128 and ppo.policy.views["mlp_extractor.policy_net.0.weight"].shape == (256, 80)
-    ppo.collect_rollouts()
+    for _ in range(12):                      # 120-step episodes: a few 16-step rollouts until episodes end inside one
+        ppo.collect_rollouts()
+        if (ppo.done_buf & 3).any():
+            break
     T, N = 16, 128
     obs = ppo.obs_buf[:T].reshape(T * N, 128)
     assert torch.all(obs[:, 80:] == 0) and torch.isfinite(obs).all()
