@@ -138,7 +138,7 @@ PolicyFn = Callable[[torch.Tensor], torch.Tensor]
 
 
 def _roll_one(env: RouteVecEnv, policy: PolicyFn, *, initial_q: np.ndarray, goal_index: int, initial_dq: np.ndarray, initial_prev_action: np.ndarray,
-              success_dwell_steps: int) -> dict[str, Any]:
+              success_dwell_steps: int, record: list[tuple[np.ndarray, np.ndarray]] | None = None) -> dict[str, Any]:
     obs = env.reset(options={"route_index": int(goal_index), "start_route_index": 0, "initial_q": initial_q[None], "initial_dq": initial_dq[None],
                              "initial_prev_action": initial_prev_action[None], "evaluator_state": True})
     info = env.info()
@@ -151,6 +151,8 @@ def _roll_one(env: RouteVecEnv, policy: PolicyFn, *, initial_q: np.ndarray, goal
     done = 0
     while not (done & 3):
         action = policy(obs)
+        if record is not None:   # the observation the action was computed from (collect_route_teacher_rollout.py:68-73)
+            record.append((obs[0, :env.obs_dim].cpu().numpy().astype(np.float32), action[0].detach().cpu().numpy().astype(np.float32)))
         obs, _, d = env.step(action, auto_reset=False)
         done = int(d[0])
         steps += 1
@@ -313,4 +315,53 @@ def evaluate_route_gate(*, evaluate: Callable[..., dict[str, Any]], artifact_roo
         "prefix_results": prefix_results, "full_result": full_summary,
     }
     (root / "route_gate_summary.json").write_text(json.dumps(summary, indent=2))
+    return summary
+
+
+# --------------------------------------------------------------------------------------------- teacher-anchor dataset
+def collect_teacher_rollout(*, policy: PolicyFn, cfg: dict[str, Any], route_q: np.ndarray, artifact_root: str | Path, start_index: int = 1, end_index: int = 120,
+                            device: int = 0, checkpoint: str = "", config: str = "", route_path: str = "") -> dict[str, Any]:
+    """route/collect_route_teacher_rollout.py:22-123: the sequential evaluator's chained episodes with every (observation, action) pair
+    recorded; the walk stops at the first failed waypoint and that episode's samples are dropped.  Writes
+    ``teacher_route_anchor_dataset.npz`` (``obs__<key>``, ``actions``, ``route_index``, ``step``) + the summary JSON."""
+    W = int(route_q.shape[0])
+    seq_off = {**cfg, "route": {**(cfg.get("route", {}) or {}), "sequence": {**((cfg.get("route", {}) or {}).get("sequence", {}) or {}), "enabled": False}}}
+    base = kcfg.to_env_config(cfg)
+    env = RouteVecEnv(base, rcfg.route_config_from_dict(seq_off, max_route_index=end_index), route_q, 1, device=device, seed=0)
+    layout = rcfg.ROUTE_OBS_LAYOUT if env.obs_dim == rcfg.ROUTE_OBS_DIM else kcfg.OBS_LAYOUT
+    obs_rows: list[np.ndarray] = []
+    action_rows: list[np.ndarray] = []
+    meta: list[tuple[int, int]] = []
+    ok: list[int] = []
+    failed: list[int] = []
+    cq = np.asarray(route_q[max(start_index - 1, 0)], dtype=float).copy()
+    cdq, cpa = np.zeros_like(cq), np.zeros_like(cq)
+    dwell = int(base.c.termination.success_dwell_steps)
+    for idx in range(int(start_index), min(int(end_index), W - 1) + 1):
+        rec: list[tuple[np.ndarray, np.ndarray]] = []
+        row = _roll_one(env, policy, initial_q=cq, goal_index=idx, initial_dq=cdq, initial_prev_action=cpa, success_dwell_steps=dwell, record=rec)
+        cq, cdq, cpa = row["final_q"], row["final_dq"], row["final_prev_action"]
+        if not row["success"]:
+            failed.append(idx)
+            break
+        ok.append(idx)
+        for step, (o, a) in enumerate(rec):
+            obs_rows.append(o)
+            action_rows.append(a)
+            meta.append((idx, step))
+    env.close()
+    root = Path(artifact_root)
+    root.mkdir(parents=True, exist_ok=True)
+    dataset_path = root / "teacher_route_anchor_dataset.npz"
+    obs_mat = np.asarray(obs_rows, dtype=np.float32).reshape(len(obs_rows), sum(w for _, w in layout.values()))
+    arrays: dict[str, np.ndarray] = {"actions": np.asarray(action_rows, dtype=np.float32).reshape(len(action_rows), kcfg.NJ),
+                                     "route_index": np.asarray([m[0] for m in meta], dtype=np.int32), "step": np.asarray([m[1] for m in meta], dtype=np.int32)}
+    for key, (off, width) in layout.items():
+        arrays[f"obs__{key}"] = obs_mat[:, off:off + width]
+    np.savez_compressed(dataset_path, **arrays)
+    summary = {"schema_version": "v5.route_teacher_anchor_dataset.v1", "checkpoint": str(checkpoint), "config": str(config), "route_path": str(route_path),
+               "dataset_path": str(dataset_path), "start_index": int(start_index), "requested_end_index": int(end_index), "successful_indices": ok,
+               "failed_indices": failed, "sample_count": int(len(action_rows)), "obs_keys": sorted(layout.keys()),
+               "action_dim": int(kcfg.NJ) if action_rows else 0}
+    (root / "teacher_route_anchor_summary.json").write_text(json.dumps(summary, indent=2))
     return summary
