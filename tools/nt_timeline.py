@@ -96,9 +96,14 @@ if fused:
         d = np.diff(sel[:, :7], axis=1)
         print(f"net {zz}: per-phase medians (prologue, G1+tanh, G2+tanh, heads, G3+dtanh, store):", np.round(np.median(d, axis=0), 2),
               " first-round workgroups:", int((sel[:, 0] < 1.0).sum()))
-    if (t[:, 7] > 0).any():
-        g2 = us[:, [2] + list(range(7, 15))]
-        print("G2 per-stage medians (wave 0 of each workgroup, us):", np.round(np.median(np.diff(g2, axis=1), axis=0), 2))
+    if "KP1_TR_HEADS" in os.environ.get("KP1_TRACE_DEFS", ""):
+        hd = us[:, [3, 7, 8, 9, 10, 4]]
+        for zz in (0, 1):
+            sel = hd[zz * (len(us) // 2):(zz + 1) * (len(us) // 2)]
+            print(f"net {zz} head phase medians (dot products + barrier, loss math, barrier, dZ2 + head grads, barrier):", np.round(np.median(np.diff(sel, axis=1), axis=0), 2))
+    elif (t[:, 7] > 0).any():
+        g2 = us[:, [2] + list(range(7, 11))]     # slots 11.. are overwritten by the TN-frag launch that follows
+        print("G2 first stages, medians (wave 0 of each workgroup, us):", np.round(np.median(np.diff(g2, axis=1), axis=0), 2))
     sys.exit(0)
 names = ["start", "prologue_done"] + [f"stages_{2 * i}-{2 * i + 1}_done" for i in range(8)] + ["acc_in_lds", "stores_issued"]
 for i, nm in enumerate(names):
