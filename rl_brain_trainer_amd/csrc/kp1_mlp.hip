@@ -687,7 +687,9 @@ __host__ __device__ inline ParamLayout make_layout(int H, int IN = KP1_MLP_IN) {
 struct Packed {
   float *w1p, *b1, *w2, *w2t, *b2, *w3, *b3, *log_std;  // [2][2][Hp][32], [2][Hp], [2][Hp/32][Hp][32] x2, [2][Hp], [8][Hp], [8], [8]
   float *w1f, *w2f, *w2tf;                               // fragment-major copies of w1p, w2, w2t
+  int formats;                                           // which GEMM-weight copies pack_one writes: bit 0 k-slab major, bit 1 fragment major
 };
+constexpr int PACK_SLAB = 1, PACK_FRAG = 2;
 __host__ __device__ inline int64_t slab_at(int64_t n, int64_t k, int64_t N) { return (k >> 5) * N * 32 + n * 32 + (k & 31); }
 __host__ __device__ inline int64_t frag_at(int64_t n, int64_t k, int64_t N) {
   return (k >> 5) * N * 32 + (n >> 5) * 1024 + ((k & 31) >> 3) * 256 + ((n & 31) + 32 * ((k & 7) >> 2)) * 4 + (k & 3);
@@ -700,30 +702,38 @@ __device__ __forceinline__ void pack_one(int64_t i, float v, const ParamLayout& 
     k.log_std[i] = v;
   } else if (i < L.p_b1) {
     const int64_t e = i - L.p_w1;
-    k.w1p[slab_at(e / IN, e % IN, Hp)] = v;
-    k.w1f[frag_at(e / IN, e % IN, Hp)] = v;
+    if (k.formats & PACK_SLAB) k.w1p[slab_at(e / IN, e % IN, Hp)] = v;
+    if (k.formats & PACK_FRAG) k.w1f[frag_at(e / IN, e % IN, Hp)] = v;
   } else if (i < L.p_w2) {
     k.b1[i - L.p_b1] = v;
   } else if (i < L.p_b2) {
     const int64_t e = i - L.p_w2, r = e / H, c = e % H;
-    k.w2[slab_at(r, c, Hp)] = v;
-    k.w2t[slab_at(c, r, Hp)] = v;
-    k.w2f[frag_at(r, c, Hp)] = v;
-    k.w2tf[frag_at(c, r, Hp)] = v;
+    if (k.formats & PACK_SLAB) {
+      k.w2[slab_at(r, c, Hp)] = v;
+      k.w2t[slab_at(c, r, Hp)] = v;
+    }
+    if (k.formats & PACK_FRAG) {
+      k.w2f[frag_at(r, c, Hp)] = v;
+      k.w2tf[frag_at(c, r, Hp)] = v;
+    }
   } else if (i < L.v_w1) {
     k.b2[i - L.p_b2] = v;
   } else if (i < L.v_b1) {
     const int64_t e = i - L.v_w1;
-    k.w1p[(int64_t)Hp * INP + slab_at(e / IN, e % IN, Hp)] = v;
-    k.w1f[(int64_t)Hp * INP + frag_at(e / IN, e % IN, Hp)] = v;
+    if (k.formats & PACK_SLAB) k.w1p[(int64_t)Hp * INP + slab_at(e / IN, e % IN, Hp)] = v;
+    if (k.formats & PACK_FRAG) k.w1f[(int64_t)Hp * INP + frag_at(e / IN, e % IN, Hp)] = v;
   } else if (i < L.v_w2) {
     k.b1[Hp + i - L.v_b1] = v;
   } else if (i < L.v_b2) {
     const int64_t e = i - L.v_w2, r = e / H, c = e % H;
-    k.w2[(int64_t)Hp * Hp + slab_at(r, c, Hp)] = v;
-    k.w2t[(int64_t)Hp * Hp + slab_at(c, r, Hp)] = v;
-    k.w2f[(int64_t)Hp * Hp + frag_at(r, c, Hp)] = v;
-    k.w2tf[(int64_t)Hp * Hp + frag_at(c, r, Hp)] = v;
+    if (k.formats & PACK_SLAB) {
+      k.w2[(int64_t)Hp * Hp + slab_at(r, c, Hp)] = v;
+      k.w2t[(int64_t)Hp * Hp + slab_at(c, r, Hp)] = v;
+    }
+    if (k.formats & PACK_FRAG) {
+      k.w2f[(int64_t)Hp * Hp + frag_at(r, c, Hp)] = v;
+      k.w2tf[(int64_t)Hp * Hp + frag_at(c, r, Hp)] = v;
+    }
   } else if (i < L.a_w) {
     k.b2[Hp + i - L.v_b2] = v;
   } else if (i < L.a_b) {
@@ -997,6 +1007,11 @@ struct kp1_mlp {
   int* step_dev = nullptr;     // device Adam step counter
   int last_s2_n = 0, last_s1_n = 0;
   int fused = 1;               // KP1_MLP_OPT_FUSED: one workgroup carries a row tile through the whole chain (H = 256 only)
+  // While the fused path is selected the Adam kernel refreshes only the fragment-major weight copies (the transposed / slab copies are
+  // scattered 4-byte writes and were half of the kernel's HBM write traffic); the k-slab copies are then stale until the next full pack, which switching the
+  // option off triggers from the parameter vector last seen.
+  const float* last_params = nullptr;
+  bool slab_stale = false;
   std::vector<void*> allocs;
 };
 
@@ -1233,6 +1248,16 @@ int kp1_mlp_set_option(kp1_mlp* m, int32_t option, int32_t value) {
   if (!m) return fail(KP1_ERR_INVALID, "NULL argument");
   if (option == KP1_MLP_OPT_FUSED) {
     m->fused = value ? 1 : 0;
+    if (!m->fused && m->slab_stale && m->last_params) {   // the layer-wise kernels read the k-slab copies: bring them up to date
+      HIP_TRY(hipSetDevice(m->device));
+      HIP_TRY(hipDeviceSynchronize());
+      Packed k = m->k;
+      k.formats = PACK_SLAB | PACK_FRAG;
+      hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((m->L.total + 255) / 256)), dim3(256), 0, (hipStream_t)0, m->last_params, m->L, k);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipDeviceSynchronize());
+      m->slab_stale = false;
+    }
     return KP1_OK;
   }
   if (option == KP1_MLP_OPT_ACTOR_EXTRA_STEPS) {
@@ -1248,8 +1273,12 @@ int kp1_mlp_pack_weights(kp1_mlp* m, const float* params, void* stream) {
   if (!m || !params) return fail(KP1_ERR_INVALID, "NULL argument");
   int rc = mlp_check_device(m);
   if (rc != KP1_OK) return rc;
-  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((m->L.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, m->L, m->k);
+  Packed k = m->k;
+  k.formats = PACK_SLAB | PACK_FRAG;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((m->L.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, m->L, k);
   HIP_TRY(hipGetLastError());
+  m->last_params = params;
+  m->slab_stale = false;
   return KP1_OK;
 }
 
@@ -1531,8 +1560,13 @@ int kp1_mlp_adam_step(kp1_mlp* m, float* params, float* grad, float* exp_avg, fl
   const int host_step = step > 0 ? step : 1;
   const float bc1 = 1.f - std::pow(0.9f, (float)host_step);
   const float bc2 = 1.f - std::pow(0.999f, (float)host_step);
+  Packed kfmt = m->k;
+  const bool frag_only = m->fused && m->Hp == FU_HP;
+  kfmt.formats = frag_only ? PACK_FRAG : (PACK_SLAB | PACK_FRAG);
+  m->last_params = params;
+  if (frag_only) m->slab_stale = true;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, params, grad, exp_avg, exp_avg_sq, n,
-                     norm_partials, n_norm_partials, lr, eps, max_grad_norm, bc1, std::sqrt(bc2), m->L, m->k, zero_grad,
+                     norm_partials, n_norm_partials, lr, eps, max_grad_norm, bc1, std::sqrt(bc2), m->L, kfmt, zero_grad,
                      step > 0 ? (const int*)nullptr : (const int*)m->step_dev, host_step, (const int*)m->step_dev + 1);
   HIP_TRY(hipGetLastError());
   return KP1_OK;

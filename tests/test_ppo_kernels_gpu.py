@@ -298,3 +298,24 @@ def test_compacted_truncation_bootstrap_matches_dense_path():
     assert torch.equal((ppo.rew_buf != raw), trunc)
     assert torch.allclose(ppo.rew_buf, dense, rtol=0, atol=1e-6)
     env.close()
+
+
+def test_layerwise_weight_copies_follow_adam_after_option_switch():
+    """While the fused path is selected kp1_mlp_adam_step refreshes only the fragment-major weight copies; switching to the layer-wise
+    kernels must first bring their k-slab copies up to date (KP1_MLP_OPT_FUSED, kp1_mlp_set_option)."""
+    pol = _policy()
+    k = MlpKernels(256, DEV, max_batch=4096)
+    k.pack(pol.flat)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    m = torch.zeros_like(pol.flat)
+    v = torch.zeros_like(pol.flat)
+    for step in (1, 2, 3):
+        grad = 1e-2 * torch.randn(pol.flat.numel(), device=DEV, generator=g)
+        k.adam_step(pol.flat, grad, m, v, lr=1e-2, eps=1e-5, max_grad_norm=0.5, step=step)
+    obs = torch.rand((512, 56), device=DEV, generator=g) * 2 - 1
+    ref_mean, ref_value = P.mlp_forward(pol.views, obs)
+    for fused in (True, False, True):
+        k.set_fused(fused)
+        mean, value = k.mean_value(obs)
+        assert torch.allclose(mean, ref_mean, rtol=1e-4, atol=2e-5) and torch.allclose(value, ref_value, rtol=1e-4, atol=2e-5), fused
+    k.close()
