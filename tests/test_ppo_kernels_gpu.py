@@ -319,3 +319,55 @@ def test_layerwise_weight_copies_follow_adam_after_option_switch():
         mean, value = k.mean_value(obs)
         assert torch.allclose(mean, ref_mean, rtol=1e-4, atol=2e-5) and torch.allclose(value, ref_value, rtol=1e-4, atol=2e-5), fused
     k.close()
+
+
+def test_ppo_optimiser_step_matches_cpu_oracle():
+    """One full optimiser step (MFMA loss / gradient, clip_grad_norm_, Adam, weight repack) against oracle/ppo_oracle.py, the CPU
+    restatement of SB3's PPO.train inner loop, from the same parameters on the same minibatch.  fp32 both sides; tolerance = the
+    summation-order differences of the gradient (2e-4 of its scale) carried through one Adam step."""
+    from oracle import ppo_oracle as po
+
+    cpu = po.ActorCriticCPU(56, 256, 7, seed=4)
+    with torch.no_grad():
+        cpu.log_std.copy_(torch.tensor([-0.3, 0.1, -0.5, 0.0, 0.2, -0.1, -0.7]))
+        cpu.action_head.weight.mul_(10.0)
+    pol = P.ActorCritic(256, DEV, seed=0)
+    pol.flat.copy_(po.flat_params_sb3_order(cpu).to(DEV))
+    k = MlpKernels(256, DEV, max_batch=8192)
+    k.pack(pol.flat)
+    g = torch.Generator().manual_seed(12)
+    n = 4096
+    obs = torch.rand((n, 56), generator=g) * 2 - 1
+    with torch.no_grad():
+        mean, values = cpu(obs)
+    act = mean + torch.exp(cpu.log_std.detach()) * torch.randn((n, 7), generator=g)
+    old = cpu.log_prob(act, mean + 0.05 * torch.randn((n, 7), generator=g)).detach()
+    adv = torch.randn(n, generator=g) * 2 + 0.3
+    ret = values + torch.randn(n, generator=g)
+    lr, clip, ent, vf = 1e-3, 0.1, 3e-4, 0.5
+    opt = torch.optim.Adam(cpu.parameters(), lr=lr, eps=1e-5)
+    before = po.flat_params_sb3_order(cpu).clone()
+    terms = po.train_minibatch(cpu, opt, obs, act, old, adv, ret, clip_range=clip, ent_coef=ent, vf_coef=vf, max_grad_norm=0.5)
+    after = po.flat_params_sb3_order(cpu)
+
+    d = lambda t: t.to(DEV).contiguous()   # noqa: E731
+    grad = torch.empty(k.num_params, device=DEV)
+    stats = torch.zeros(4, device=DEV)
+    m, v = torch.zeros_like(pol.flat), torch.zeros_like(pol.flat)
+    k.loss_grad(d(obs), None, n, d(act), d(old), d(adv), d(ret), clip_range=clip, ent_coef=ent, vf_coef=vf, inv_count=1.0 / n, grad_out=grad, stats_out=stats)
+    k.adam_step(pol.flat, grad, m, v, lr=lr, eps=1e-5, max_grad_norm=0.5, step=1, fused_norm=True)
+    assert abs(stats[0].item() - terms["policy_loss"]) <= 1e-4 * (1 + abs(terms["policy_loss"]))
+    assert abs(stats[1].item() - terms["value_loss"]) <= 1e-4 * (1 + abs(terms["value_loss"]))
+    delta_ref = (after - before).to(DEV)
+    delta = pol.flat - before.to(DEV)
+    # first Adam step: delta = -lr * g / (|g| + eps) -- about lr * sign(g) wherever |g| >> eps = 1e-5, and sensitive to the last bits of g
+    # where |g| ~ eps (d delta / d g = lr * eps / (|g| + eps)^2): bound the bulk tightly and the eps-sized gradients loosely
+    err = (delta - delta_ref).abs()
+    assert torch.quantile(err, 0.99).item() <= 2e-2 * lr and err.max().item() <= 0.3 * lr, (torch.quantile(err, 0.99).item(), err.max().item())
+    big = delta_ref.abs() > 0.5 * lr
+    assert big.float().mean() > 0.5 and torch.equal(torch.sign(delta[big]), torch.sign(delta_ref[big]))
+    mean2, value2 = k.mean_value(d(obs))
+    with torch.no_grad():
+        rm, rv = cpu(obs)
+    assert torch.allclose(mean2.cpu(), rm, rtol=1e-3, atol=2e-4) and torch.allclose(value2.cpu(), rv, rtol=1e-3, atol=2e-4)
+    k.close()
