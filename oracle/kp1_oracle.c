@@ -1244,6 +1244,12 @@ int kp1o_max_threads(void) {
 }
 void kp1o_batch_step(kp1o_env* envs, int n, const double* actions, float* obs, double* reward, uint8_t* done,
                      int auto_reset, int n_threads) {
+  kp1o_batch_step_components(envs, n, actions, obs, reward, done, auto_reset, n_threads, 0);
+}
+
+/* same, also returning every env's reward components [n][KP1O_MAX_COMPONENTS] (NULL = skip) */
+void kp1o_batch_step_components(kp1o_env* envs, int n, const double* actions, float* obs, double* reward, uint8_t* done,
+                                int auto_reset, int n_threads, double* components) {
   (void)n_threads;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(n_threads > 0 ? n_threads : omp_get_max_threads())
@@ -1255,6 +1261,7 @@ void kp1o_batch_step(kp1o_env* envs, int n, const double* actions, float* obs, d
     uint8_t d = (uint8_t)((so.terminated ? KP1_DONE_TERMINATED : 0) | (so.truncated ? KP1_DONE_TRUNCATED : 0) |
                           (so.success ? KP1_DONE_SUCCESS : 0) | (so.invalid ? KP1_DONE_INVALID : 0));
     done[i] = d;
+    if (components) memcpy(components + (size_t)i * KP1O_MAX_COMPONENTS, so.components, sizeof so.components);
     if (auto_reset && (so.terminated || so.truncated)) kp1o_env_reset(&envs[i], 0, obs + KP1_OBS_DIM * (size_t)i);
   }
 }
@@ -1269,4 +1276,26 @@ size_t kp1o_offsetof_env(int which) {
     case 3: return offsetof(kp1o_env, goal_pose6);
     default: return offsetof(kp1o_env, last_reset_stage);
   }
+}
+
+
+/* Stand-alone evaluation of the two reward functions with caller-supplied arguments (the way the reference's own unit tests call
+ * compute_approach_reward / compute_dock_reward: tests/test_kinematic_phase1_approach_reward.py, test_kinematic_phase1_split.py).
+ * flags = {curr_in_pre_near_goal, prev_in_near_goal, curr_in_near_goal, dwell_count, near_goal_entry_count, near_goal_drift_count, success};
+ * scalars = {joint_limit_margin_min, dq_norm, prev_dq_norm, delta_q_change_l2, entry_pos, entry_ori, entry_action_l2, entry_dq_norm}. */
+double kp1o_reward_eval(const kp1_config* cfg, int mode, const double prev_pose6[6], const double curr_pose6[6], const double goal_pose6[6],
+                        const double action[7], const double prev_action[7], const int32_t flags[7], const double scalars[8],
+                        double* components, int32_t* n_components) {
+  reward_in ri;
+  ri.prev_pose6 = prev_pose6; ri.curr_pose6 = curr_pose6; ri.goal_pose6 = goal_pose6; ri.action = action; ri.prev_action = prev_action;
+  ri.curr_in_pre_near_goal = flags[0]; ri.prev_in_near_goal = flags[1]; ri.curr_in_near_goal = flags[2];
+  ri.dwell_count = flags[3]; ri.near_goal_entry_count = flags[4]; ri.near_goal_drift_count = flags[5]; ri.success = flags[6];
+  ri.joint_limit_margin_min = scalars[0]; ri.dq_norm = scalars[1]; ri.prev_dq_norm = scalars[2]; ri.delta_q_change_l2 = scalars[3];
+  ri.entry_pos = scalars[4]; ri.entry_ori = scalars[5]; ri.entry_action = scalars[6]; ri.entry_dq = scalars[7];
+  if (mode == KP1_MODE_DOCK) {
+    *n_components = N_DOCK_COMPONENTS;
+    return compute_dock_reward(&cfg->dock_reward, &ri, components);
+  }
+  *n_components = N_APPROACH_COMPONENTS;
+  return compute_approach_reward(&cfg->reward, &ri, components);
 }

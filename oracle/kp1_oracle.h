@@ -98,6 +98,10 @@ void kp1o_env_step(kp1o_env* e, const double action[7], float obs[KP1_OBS_DIM], 
 void kp1o_env_observe(const kp1o_env* e, float obs[KP1_OBS_DIM]);
 void kp1o_env_capture_entry_metrics(kp1o_env* e);
 const char* kp1o_component_name(int mode, int index);
+/* compute_approach_reward / compute_dock_reward with caller-supplied arguments (reward_approach.py:75-373, reward_dock.py:123-484) */
+double kp1o_reward_eval(const kp1_config* cfg, int mode, const double prev_pose6[6], const double curr_pose6[6], const double goal_pose6[6],
+                        const double action[7], const double prev_action[7], const int32_t flags[7], const double scalars[8],
+                        double* components, int32_t* n_components);
 int kp1o_num_components(int mode);
 
 /* curriculum tracker; curriculum.py:104-154 / callbacks.py:32-101 */
@@ -118,6 +122,8 @@ size_t kp1o_offsetof_env(int which);
 int kp1o_max_threads(void);
 void kp1o_batch_step(kp1o_env* envs, int n, const double* actions /*[n][7]*/, float* obs /*[n][56]*/,
                      double* reward, uint8_t* done, int auto_reset, int n_threads);
+void kp1o_batch_step_components(kp1o_env* envs, int n, const double* actions, float* obs, double* reward, uint8_t* done, int auto_reset,
+                                int n_threads, double* components /*[n][KP1O_MAX_COMPONENTS] or NULL*/);
 
 #ifdef __cplusplus
 }

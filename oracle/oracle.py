@@ -134,6 +134,7 @@ def lib() -> C.CDLL:
         for k, name in enumerate(("rng", "handoff", "min_pos_error", "goal_pose6", "last_reset_stage")):
             assert L.kp1o_offsetof_env(k) == getattr(OEnv, name).offset, name
         L.kp1o_batch_step.argtypes = [C.POINTER(OEnv), C.c_int, dp, C.POINTER(C.c_float), dp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
+        L.kp1o_batch_step_components.argtypes = [C.POINTER(OEnv), C.c_int, dp, C.POINTER(C.c_float), dp, C.POINTER(C.c_uint8), C.c_int, C.c_int, dp]
         _lib = L
     return _lib
 
@@ -276,9 +277,16 @@ class OracleVecEnv:
     def step(self, actions: np.ndarray, auto_reset: bool = True, n_threads: int = 0):
         a = np.ascontiguousarray(actions, dtype=np.float64)
         assert a.shape == (self.n, kcfg.NJ)
-        self.L.kp1o_batch_step(self.envs, self.n, _dp(a), self.obs.ctypes.data_as(C.POINTER(C.c_float)), _dp(self.reward),
-                               self.done.ctypes.data_as(C.POINTER(C.c_uint8)), int(auto_reset), n_threads)
+        if getattr(self, "_components", None) is None:
+            self._components = np.zeros((self.n, MAX_COMPONENTS))
+        self.L.kp1o_batch_step_components(self.envs, self.n, _dp(a), self.obs.ctypes.data_as(C.POINTER(C.c_float)), _dp(self.reward),
+                                          self.done.ctypes.data_as(C.POINTER(C.c_uint8)), int(auto_reset), n_threads, _dp(self._components))
         return self.obs, self.reward, self.done
+
+    def components(self) -> np.ndarray:
+        """reward components of the last step, [n_envs, n_components of this mode]"""
+        mode = int(self.cfg.c.env.mode) if hasattr(self.cfg.c.env, "mode") else 0
+        return self._components[:, :self.L.kp1o_num_components(mode)]
 
     def field(self, name: str) -> np.ndarray:
         return np.array([np.array(getattr(self.envs[i], name)) for i in range(self.n)])

@@ -284,3 +284,47 @@ def test_error_behaviour():
     env.set_curriculum_stage(99)
     assert env.get_curriculum_stage() == cfg.n_stages - 1      # clipped; :446-449
     env.close()
+
+
+@pytest.mark.parametrize("mode,case_ids", [("approach", (0, 17, 41, 63, 88, 119)), ("dock", (120, 133, 160, 201, 239, 245))])
+def test_random_reward_config_parity_vs_oracle_f64(mode, case_ids):
+    """Device env (f64) vs the oracle env with every reward weight / threshold randomised (the configs of tests/golden/reward_fuzz.json, on
+    which the oracle's reward functions are pinned to the reference): total reward and every reward component per env and step, done bits
+    exact.  The shipped YAML configs leave many reward terms at 0; this is the device-side check of those terms."""
+    import json
+
+    from conftest import GOLDEN
+
+    cases = json.loads((GOLDEN / "reward_fuzz.json").read_text())["cases"]
+    base_name = "workspace_expansion_bigtrain" if mode == "approach" else "dock_workspace_handoff_noop_ft_12env_raw"
+    block = "reward" if mode == "approach" else "dock_reward"
+    n, seed, steps = 256, 4242, 140
+    for cid in case_ids:
+        case = cases[cid]
+        assert case["mode"] == mode
+        cfgd = json.loads((GOLDEN / "configs" / f"{base_name}.json").read_text())
+        cfgd["env"][block] = dict(case["config"])
+        cfg = kcfg.to_env_config(cfgd, handoff_base_dirs=(GOLDEN,))
+        stage = 5 if mode == "approach" else 0
+        env = ArmKinematicVecEnv(cfg, n, seed=seed, real="f64", reward_components=True)
+        env.set_curriculum_stage(stage)
+        ora = orc.OracleVecEnv(cfg, n, seed0=seed, stage=stage)
+        env.reset()
+        ora.reset()
+        arng = np.random.default_rng(cid)
+        dl = np.array(cfg.c.joints.delta_limit[:]) * (cfg.c.env.dock_action_delta_scale or cfg.c.env.action_delta_scale)
+        worst_r = worst_c = 0.0
+        for t in range(steps):
+            a = arng.uniform(-1.2, 1.2, size=(n, 7))
+            servo = 0.8 * (ora.field("goal_q") - ora.field("q")) / dl + arng.uniform(-0.02, 0.02, size=(n, 7))
+            a[: 3 * n // 4] = servo[: 3 * n // 4]            # most envs converge so the near-goal / dwell / readiness terms fire
+            _, rg, dg = env.step(torch.tensor(a, dtype=torch.float64, device="cuda"))
+            _, ro, do = ora.step(a)
+            assert np.array_equal(dg.cpu().numpy(), do), (cid, t)
+            worst_r = max(worst_r, float(np.max(np.abs(rg.cpu().numpy() - ro))))
+            names, comps = env.reward_components()
+            oc = ora.components()
+            assert comps.shape[0] == oc.shape[1] == len(names)
+            worst_c = max(worst_c, float(np.max(np.abs(comps.cpu().numpy().T - oc))))
+        assert worst_r <= 1e-9 and worst_c <= 1e-9, (cid, worst_r, worst_c)
+        env.close()

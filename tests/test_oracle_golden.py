@@ -235,3 +235,62 @@ def test_reference_env_unit_behaviours():
     assert np.allclose(orc.fk_pose6(st["goal_q"])[0], st["goal_pose6"], atol=1e-8)
     with pytest.raises(ValueError):
         env.step(np.zeros(6))
+
+
+def _reward_eval(case):
+    """oracle compute_*_reward on one fixture case -> (total, {component: value})"""
+    import ctypes as C
+
+    mode = case["mode"]
+    block = "reward" if mode == "approach" else "dock_reward"
+    cfg = kcfg.to_env_config({"env": {"mode": mode, block: dict(case["config"])}})
+    L = orc.lib()
+    dp = C.POINTER(C.c_double)
+    L.kp1o_reward_eval.restype = C.c_double
+    L.kp1o_reward_eval.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, C.POINTER(C.c_int32), dp, dp, C.POINTER(C.c_int32)]
+    i = case["inputs"]
+
+    def arr(v):
+        return (C.c_double * len(v))(*[float(x) for x in v])
+
+    flags = (C.c_int32 * 7)(int(i["curr_in_pre_near_goal"]), int(i["prev_in_near_goal"]), int(i["curr_in_near_goal"]), int(i["dwell_count"]),
+                            int(i["near_goal_entry_count"]), int(i["near_goal_drift_count"]), int(i["success"]))
+    scalars = arr([i["joint_limit_margin_min"], i["dq_norm"], i["prev_dq_norm"], i["delta_q_change_l2"], i["entry_pos_error_norm"], i["entry_ori_error_norm"],
+                   i["entry_action_l2"], i["entry_dq_norm"]])
+    comps = (C.c_double * orc.MAX_COMPONENTS)()
+    n = C.c_int32(0)
+    mode_id = 1 if mode == "dock" else 0
+    total = L.kp1o_reward_eval(C.byref(cfg.c), mode_id, arr(i["prev_pose6"]), arr(i["curr_pose6"]), arr(i["goal_pose6"]), arr(i["action"]), arr(i["prev_action"]),
+                               flags, scalars, comps, C.byref(n))
+    L.kp1o_component_name.restype = C.c_char_p
+    names = [L.kp1o_component_name(mode_id, k).decode() for k in range(n.value)]
+    return total, dict(zip(names, list(comps)[:n.value]))
+
+
+def test_reward_functions_under_random_configs_golden():
+    """compute_approach_reward / compute_dock_reward with EVERY config field randomised (tests/golden/make_golden_reward_fuzz.py ran the
+    reference's functions): total and each of the 50 / 60 components to 1e-12, every component non-zero in some case -- the YAML configs
+    of the step traces leave many of these weights at 0.  Plus the reference's own five reward unit tests with the constants they assert."""
+    data = json.loads((GOLDEN / "reward_fuzz.json").read_text())
+    seen = set()
+    worst = 0.0
+    for case in data["cases"] + data["reference_unit_cases"]:
+        total, comps = _reward_eval(case)
+        assert set(comps) == set(case["components"]), case["mode"]
+        assert abs(total - case["reward"]) <= 1e-12 * max(1.0, abs(case["reward"])), (case["mode"], total, case["reward"])
+        for k, v in case["components"].items():
+            err = abs(comps[k] - v)
+            worst = max(worst, err / max(1.0, abs(v)))
+            assert err <= 1e-12 * max(1.0, abs(v)), (case["mode"], k, comps[k], v)
+            if v != 0.0:
+                seen.add((case["mode"], k))
+        for k, v in case.get("expect", {}).items():
+            assert comps[k] == v, (case.get("name"), k, comps[k], v)       # known answers of tests/test_kinematic_phase1_approach_reward.py
+    all_names = {(c["mode"], k) for c in data["cases"] for k in c["components"]}
+    assert seen == all_names
+    u = {c["name"]: _reward_eval(c)[1] for c in data["reference_unit_cases"]}
+    assert u["near_field_orientation_near"]["orientation_progress"] > u["near_field_orientation_far"]["orientation_progress"]
+    assert u["near_field_orientation_near"]["near_field_orientation_progress"] > 0.0
+    assert u["coarse_orientation_bonus_good"]["coarse_orientation_bonus"] > 0.0 and u["coarse_orientation_bonus_bad"]["coarse_orientation_bonus"] == 0.0
+    assert u["drift_escalation_late"]["drift_penalty"] < u["drift_escalation_early"]["drift_penalty"]
+    assert u["drift_escalation_late"]["drift_penalty_scale"] > u["drift_escalation_early"]["drift_penalty_scale"]
