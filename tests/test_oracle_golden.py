@@ -30,6 +30,13 @@ TRACES = {
     "dock_noop_seed7": "dock_workspace_handoff_noop_ft_12env_raw",
     "dock_noop_merged_seed0": "dock_workspace_handoff_noop_ft_12env",
     "dock_default_seed123": "dock_default",
+    # randomised env-level + reward configuration (tests/golden/make_golden_env_fuzz.py)
+    "fuzz0_approach": "fuzz0_approach",
+    "fuzz1_approach": "fuzz1_approach",
+    "fuzz2_approach": "fuzz2_approach",
+    "fuzz3_dock": "fuzz3_dock",
+    "fuzz4_dock": "fuzz4_dock",
+    "fuzz5_dock": "fuzz5_dock",
 }
 RESETS = {
     "approach_default_s0": "approach_default",
