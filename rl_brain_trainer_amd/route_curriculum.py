@@ -122,10 +122,12 @@ class RoutePrefixCurriculum:
 
     def observe_step(self, env: RouteVecEnv, done_bits: torch.Tensor) -> bool:
         """PPO.step_callback form: ``done_bits`` = the rollout buffer row of this step (step_into does not fill env.done)."""
-        done = done_bits.cpu().numpy()
-        info = env.info()
-        return self.on_step((done & 3) != 0, (done & 4) != 0, info["route_ready"].cpu().numpy(), info["route_orientation_hit"].cpu().numpy(),
-                            info["route_regression"].cpu().numpy())
+        packed = torch.cat([done_bits.view(1, -1), env.episode_flags()]).cpu().numpy()     # one device->host copy per step
+        done = packed[0]
+        if not (done & 3).any():
+            self.num_timesteps += len(done)
+            return True
+        return self.on_step((done & 3) != 0, (done & 4) != 0, packed[1], packed[2], packed[3])
 
     def summary(self) -> dict[str, object]:
         stage = self.stages[self.current_stage_index]

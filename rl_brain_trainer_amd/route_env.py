@@ -207,6 +207,15 @@ class RouteVecEnv:
         out["route_chunk_id"] = torch.as_tensor(self.chunk_id[idx])
         return out
 
+    def episode_flags(self) -> torch.Tensor:
+        """[3, N] uint8 device tensor (route_ready, route_orientation_hit, route_regression) of the last step: what the prefix curriculum
+        reads per finished episode, without building the whole info dict."""
+        if getattr(self, "_flag_views", None) is None:
+            v = _RouteInfoView()
+            native.check(self.L.kp1_route_get_info(self._handle, C.byref(v)))
+            self._flag_views = tuple(_view(getattr(v, name), (self.n_envs,), "|u1", self.device) for name in ("route_ready", "orientation_hit", "route_regression"))
+        return torch.stack(self._flag_views)
+
     def enable_reward_components(self, enable: bool = True) -> None:
         native.check(self.L.kp1_route_enable_reward_components(self._handle, int(enable)))
 
