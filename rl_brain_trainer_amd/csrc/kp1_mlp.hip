@@ -1018,6 +1018,10 @@ struct kp1_mlp {
 namespace {
 
 constexpr int N_PARTIALS = 128;
+#ifndef KP1_TN_SPLIT2
+#define KP1_TN_SPLIT2 32   // batch chunks of the dW2 / dW1 partial tiles (gemm_tn_frag_kernel)
+#define KP1_TN_SPLIT1 64
+#endif
 
 // rows of the batch each TN workgroup reduces: aim at ~256 workgroups (one per CU) for the H x H gradient
 int tn_chunk_rows(int n, int tiles) {
@@ -1391,8 +1395,8 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
     t.slab1 = m->slab1; t.s1_net = (int64_t)Hp * INP; t.s1_chunk = 2 * t.s1_net;
     t.groups = (n + FU_BM - 1) / FU_BM * (FU_BM / 8);
     auto up8 = [](int v) { return (v + 7) / 8 * 8; };
-    t.cg2 = up8((t.groups + 31) / 32);   // ~32 chunks x 8 tiles = one dW2 workgroup per CU
-    t.cg1 = up8((t.groups + 63) / 64);   // ~64 chunks x 4 tiles of quarter-size dW1 workgroups
+    t.cg2 = up8((t.groups + KP1_TN_SPLIT2 - 1) / KP1_TN_SPLIT2);   // ~32 chunks x 8 tiles = one dW2 workgroup per CU
+    t.cg1 = up8((t.groups + KP1_TN_SPLIT1 - 1) / KP1_TN_SPLIT1);   // ~64 chunks x 4 tiles of quarter-size dW1 workgroups
     t.n_chunks2 = (t.groups + t.cg2 - 1) / t.cg2;
     t.n_chunks1 = (t.groups + t.cg1 - 1) / t.cg1;
     rc = launch_tn_frag(t, stream);
@@ -1490,8 +1494,8 @@ int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32
         t.slab2 = m->slab; t.s2_net = (int64_t)Hp * Hp; t.s2_chunk = 2 * t.s2_net;
         t.slab1 = m->slab1; t.s1_net = (int64_t)Hp * INP; t.s1_chunk = 2 * t.s1_net;
         t.groups = (n + FU_BM - 1) / FU_BM * (FU_BM / 8);
-        t.cg2 = ((t.groups + 31) / 32 + 7) / 8 * 8;
-        t.cg1 = ((t.groups + 63) / 64 + 7) / 8 * 8;
+        t.cg2 = ((t.groups + KP1_TN_SPLIT2 - 1) / KP1_TN_SPLIT2 + 7) / 8 * 8;
+        t.cg1 = ((t.groups + KP1_TN_SPLIT1 - 1) / KP1_TN_SPLIT1 + 7) / 8 * 8;
         t.n_chunks2 = (t.groups + t.cg2 - 1) / t.cg2;
         t.n_chunks1 = (t.groups + t.cg1 - 1) / t.cg1;
         if (launch_tn_frag(t, stream) != KP1_OK) return KP1_ERR_NO_DEVICE;
