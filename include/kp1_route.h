@@ -109,6 +109,41 @@ int kp1_route_rng_get(kp1_route* r, kp1_rng_state* out_host);
 int kp1_route_rng_set(kp1_route* r, const kp1_rng_state* in_host);
 void kp1_route_config_default(kp1_route_config* cfg);
 
+/* ---- prefix curriculum on the device (route/route_curriculum.py:23-132, RoutePrefixCurriculumCallback) ----------------
+ * The callback scans the finished episodes of every VecEnv step in env order, appends (success, route_ready, orientation hit, regression)
+ * to four windows and promotes to the next prefix when the four window rates pass; promotion calls set_route_window(max = prefix, min = 1)
+ * on all envs.  kp1_route_curriculum_observe does that scan on the device after each kp1_route_step (same stream): it reads the done
+ * bytes the caller passes and the wrapper's own per-env flags, and on promotion rewrites the reset window in the device-resident route
+ * config, so the rollout needs no host synchronisation and can be replayed from a hipGraph. */
+#define KP1_ROUTE_CURRICULUM_MAX_STAGES 16
+#define KP1_ROUTE_CURRICULUM_MAX_WINDOW 1024
+#define KP1_ROUTE_CURRICULUM_MAX_HISTORY 32
+typedef struct kp1_route_curriculum_event {
+  int64_t total_timesteps;
+  int32_t from_stage, to_stage, from_prefix_end_index, to_prefix_end_index;
+  double recent_success_rate, recent_route_ready_hit_rate, recent_orientation_hit_rate, recent_regression_rate;
+} kp1_route_curriculum_event;
+typedef struct kp1_route_curriculum_state {
+  int32_t stage_index, stage_episode_count, ring_len, ring_head;
+  int32_t window_episodes, min_episodes_per_stage, n_stages, n_events;
+  int32_t prefix_end_index[KP1_ROUTE_CURRICULUM_MAX_STAGES];
+  int32_t ring_sums[4]; /* running sums of the four windows (the callback recomputes the means per finished episode) */
+  double promotion_success_rate, promotion_route_ready_hit_rate, promotion_orientation_hit_rate, promotion_max_regression_rate;
+  int64_t num_timesteps;
+  uint8_t ring[4][KP1_ROUTE_CURRICULUM_MAX_WINDOW]; /* successes, ready_hits, orientation_hits, regressions */
+  kp1_route_curriculum_event events[KP1_ROUTE_CURRICULUM_MAX_HISTORY];
+} kp1_route_curriculum_state;
+
+/* allocate the tracker in device memory and apply the first stage's window (_on_training_start) */
+int kp1_route_curriculum_create(kp1_route* r, const int32_t* prefix_end_index, int32_t n_stages, double promotion_success_rate,
+                                double promotion_route_ready_hit_rate, double promotion_orientation_hit_rate, double promotion_max_regression_rate,
+                                int32_t window_episodes, int32_t min_episodes_per_stage, kp1_route_curriculum_state** out_dev);
+int kp1_route_curriculum_destroy(kp1_route* r, kp1_route_curriculum_state* st_dev);
+/* _on_step: dones[0..N) = the KP1_DONE_* bytes kp1_route_step just wrote; steps_per_call = env steps this call stands for */
+int kp1_route_curriculum_observe(kp1_route* r, kp1_route_curriculum_state* st_dev, const uint8_t* dones, int32_t steps_per_call, void* stream);
+/* copy the tracker to the host (synchronises the stream) and bring the host copy of the reset window up to date */
+int kp1_route_curriculum_read(kp1_route* r, const kp1_route_curriculum_state* st_dev, kp1_route_curriculum_state* out_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

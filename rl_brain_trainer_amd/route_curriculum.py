@@ -8,6 +8,8 @@ what SB3 hands ``_on_step`` -- and calls ``env.set_route_window`` on promotion. 
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import json
 from collections import deque
 from dataclasses import dataclass
@@ -133,6 +135,106 @@ class RoutePrefixCurriculum:
         stage = self.stages[self.current_stage_index]
         return {"stage_index": int(self.current_stage_index), "stage_name": stage.name, "prefix_end_index": int(stage.prefix_end_index),
                 "stage_episode_count": int(self.stage_episode_count), **self._metrics(), "history": list(self.history)}
+
+
+# --------------------------------------------------------------------------------------------- the same callback on the device
+MAX_STAGES, MAX_WINDOW, MAX_HISTORY = 16, 1024, 32
+
+
+class _CurriculumEvent(C.Structure):
+    _fields_ = [("total_timesteps", C.c_int64), ("from_stage", C.c_int32), ("to_stage", C.c_int32), ("from_prefix_end_index", C.c_int32),
+                ("to_prefix_end_index", C.c_int32), ("recent_success_rate", C.c_double), ("recent_route_ready_hit_rate", C.c_double),
+                ("recent_orientation_hit_rate", C.c_double), ("recent_regression_rate", C.c_double)]
+
+
+class _CurriculumState(C.Structure):
+    _fields_ = [("stage_index", C.c_int32), ("stage_episode_count", C.c_int32), ("ring_len", C.c_int32), ("ring_head", C.c_int32),
+                ("window_episodes", C.c_int32), ("min_episodes_per_stage", C.c_int32), ("n_stages", C.c_int32), ("n_events", C.c_int32),
+                ("prefix_end_index", C.c_int32 * MAX_STAGES), ("ring_sums", C.c_int32 * 4), ("promotion_success_rate", C.c_double), ("promotion_route_ready_hit_rate", C.c_double),
+                ("promotion_orientation_hit_rate", C.c_double), ("promotion_max_regression_rate", C.c_double), ("num_timesteps", C.c_int64),
+                ("ring", (C.c_uint8 * MAX_WINDOW) * 4), ("events", _CurriculumEvent * MAX_HISTORY)]
+
+
+class RoutePrefixCurriculumDevice:
+    """RoutePrefixCurriculum with the per-step scan on the device (include/kp1_route.h, kp1_route_curriculum_*): same promotion rule and
+    history, no host synchronisation per step, so the PPO rollout stays one hipGraph replay.  Plugs into ``PPO(curriculum=...)``."""
+
+    def __init__(self, *, stages: list[RouteCurriculumStage], promotion_success_rate: float, promotion_route_ready_hit_rate: float,
+                 promotion_orientation_hit_rate: float, promotion_max_regression_rate: float, window_episodes: int, min_episodes_per_stage: int = 128) -> None:
+        if not stages:
+            raise ValueError("RoutePrefixCurriculumCallback requires at least one stage")
+        if len(stages) > MAX_STAGES or int(window_episodes) > MAX_WINDOW:
+            raise ValueError(f"the device tracker holds at most {MAX_STAGES} stages and a window of {MAX_WINDOW} episodes")
+        self.stages = list(stages)
+        self._args = (float(promotion_success_rate), float(promotion_route_ready_hit_rate), float(promotion_orientation_hit_rate),
+                      float(promotion_max_regression_rate), max(int(window_episodes), 1), max(int(min_episodes_per_stage), 1))
+        self.env: RouteVecEnv | None = None
+        self._st = C.c_void_p()
+
+    @classmethod
+    def from_config(cls, cfg: dict[str, Any], n_waypoints: int) -> "RoutePrefixCurriculumDevice":
+        host = RoutePrefixCurriculum.from_config(cfg, n_waypoints)
+        return cls(stages=host.stages, promotion_success_rate=host.promotion_success_rate, promotion_route_ready_hit_rate=host.promotion_route_ready_hit_rate,
+                   promotion_orientation_hit_rate=host.promotion_orientation_hit_rate, promotion_max_regression_rate=host.promotion_max_regression_rate,
+                   window_episodes=host.window_episodes, min_episodes_per_stage=host.min_episodes_per_stage)
+
+    def attach(self, env: RouteVecEnv) -> None:
+        """_on_training_start: allocate the tracker next to the env and apply the first prefix."""
+        from . import native
+
+        self.env = env
+        L = env.L
+        vp, i32, f64 = C.c_void_p, C.c_int32, C.c_double
+        L.kp1_route_curriculum_create.argtypes = [vp, C.POINTER(i32), i32, f64, f64, f64, f64, i32, i32, C.POINTER(vp)]
+        L.kp1_route_curriculum_destroy.argtypes = [vp, vp]
+        L.kp1_route_curriculum_observe.argtypes = [vp, vp, vp, i32, vp]
+        L.kp1_route_curriculum_read.argtypes = [vp, vp, C.POINTER(_CurriculumState), vp]
+        prefixes = (i32 * len(self.stages))(*[int(s.prefix_end_index) for s in self.stages])
+        with torch.cuda.device(env.device):
+            native.check(L.kp1_route_curriculum_create(env._handle, prefixes, len(self.stages), *self._args, C.byref(self._st)))
+        env.route_cfg.reset.min_route_index, env.route_cfg.reset.max_route_index = 1, int(self.stages[0].prefix_end_index)
+
+    def observe(self, dones: torch.Tensor, steps_per_call: int) -> None:
+        from . import native
+
+        if dones.numel() != self.env.n_envs:
+            raise ValueError("the device route curriculum tracks one process's envs (no data-parallel gather of the route flags)")
+        stream = torch.cuda.current_stream(self.env.device).cuda_stream
+        native.check(self.env.L.kp1_route_curriculum_observe(self.env._handle, self._st, C.c_void_p(dones.data_ptr()), int(steps_per_call), C.c_void_p(stream)))
+
+    def read(self) -> _CurriculumState:
+        from . import native
+
+        out = _CurriculumState()
+        stream = torch.cuda.current_stream(self.env.device).cuda_stream
+        native.check(self.env.L.kp1_route_curriculum_read(self.env._handle, self._st, C.byref(out), C.c_void_p(stream)))
+        self.env.route_cfg.reset.min_route_index, self.env.route_cfg.reset.max_route_index = 1, int(out.prefix_end_index[out.stage_index])
+        return out
+
+    def summary(self) -> dict[str, object]:
+        st = self.read()
+        n = int(st.ring_len)
+
+        def mean(q: int) -> float:
+            return float(sum(st.ring[q][k] for k in range(n))) / float(n) if n else 0.0
+
+        history = []
+        for k in range(min(int(st.n_events), MAX_HISTORY)):
+            e = st.events[k]
+            history.append({"from_stage": self.stages[e.from_stage].name, "to_stage": self.stages[e.to_stage].name,
+                            "from_prefix_end_index": int(e.from_prefix_end_index), "to_prefix_end_index": int(e.to_prefix_end_index),
+                            "total_timesteps": int(e.total_timesteps), "recent_success_rate": float(e.recent_success_rate),
+                            "recent_route_ready_hit_rate": float(e.recent_route_ready_hit_rate),
+                            "recent_orientation_hit_rate": float(e.recent_orientation_hit_rate), "recent_regression_rate": float(e.recent_regression_rate)})
+        stage = self.stages[int(st.stage_index)]
+        return {"stage_index": int(st.stage_index), "stage_name": stage.name, "prefix_end_index": int(stage.prefix_end_index),
+                "stage_episode_count": int(st.stage_episode_count), "recent_success_rate": mean(0), "recent_route_ready_hit_rate": mean(1),
+                "recent_orientation_hit_rate": mean(2), "recent_regression_rate": mean(3), "history": history}
+
+    def close(self) -> None:
+        if self.env is not None and self._st.value:
+            self.env.L.kp1_route_curriculum_destroy(self.env._handle, self._st)
+            self._st = C.c_void_p()
 
 
 # --------------------------------------------------------------------------------------------- sequential evaluator

@@ -25,7 +25,7 @@ from . import checkpoint
 from . import config as kcfg
 from . import route_config as rcfg
 from .ppo import PPO, Dist, PPOConfig
-from .route_curriculum import RoutePrefixCurriculum, evaluate_route_gate, evaluate_sequential_route
+from .route_curriculum import RoutePrefixCurriculum, RoutePrefixCurriculumDevice, evaluate_route_gate, evaluate_sequential_route
 from .route_env import RouteVecEnv
 from .teacher_anchor import RouteTeacherAnchor, TeacherAnchorConfig
 
@@ -53,6 +53,7 @@ def build_arg_parser() -> argparse.ArgumentParser:
     p.add_argument("--hidden", type=int, default=256)
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--log-every", type=int, default=0)
+    p.add_argument("--host-curriculum", action="store_true", help="run the prefix curriculum as a host callback per step (eager rollout) instead of on the device")
     return p
 
 
@@ -85,16 +86,20 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
     n_steps = int(args.n_steps or algo.get("n_steps", 2048))
     batch = int(args.batch_size or algo.get("batch_size", 64))
     pcfg = PPOConfig.from_algo_kwargs(model_kwargs, n_steps=n_steps, batch_size=batch, hidden=args.hidden)
-    ppo = PPO(env, pcfg, dist=Dist(), backend="hip" if args.hidden in (128, 256) else "torch")
+    # the prefix curriculum: a device tracker after every env step (the rollout stays one hipGraph replay), or the host callback
+    hip = args.hidden in (128, 256)
+    curriculum = (RoutePrefixCurriculum if (args.host_curriculum or not hip) else RoutePrefixCurriculumDevice).from_config(cfg, W)
+    on_device = isinstance(curriculum, RoutePrefixCurriculumDevice)
+    ppo = PPO(env, pcfg, curriculum=curriculum if on_device else None, dist=Dist(), backend="hip" if hip else "torch")
     if init_checkpoint:
         ppo.policy.load_state_dict(checkpoint.load_policy_state_dict(init_checkpoint))   # PPO.load(..., env=vec_env); the YAML's learning rate wins
         if ppo._mlp is not None:
             ppo._mlp.pack(ppo.policy.flat)
         print(f"Resuming route policy from {init_checkpoint}")
 
-    curriculum = RoutePrefixCurriculum.from_config(cfg, W)
-    curriculum.on_training_start(env)
-    ppo.step_callback = lambda done_bits: curriculum.observe_step(env, done_bits)
+    if not on_device:
+        curriculum.on_training_start(env)
+        ppo.step_callback = lambda done_bits: curriculum.observe_step(env, done_bits)
     anchor = None
     anchor_cfg = TeacherAnchorConfig(**(route_cfg.get("teacher_anchor", {}) or {}))
     if anchor_cfg.enabled:

@@ -233,3 +233,41 @@ def test_collect_teacher_rollout_feeds_the_anchor(tmp_path):
     anchor.on_rollout_end(ppo)
     assert anchor.summary()["sample_count"] == s["sample_count"] and anchor.last_loss > 0 and (ppo.policy.flat != before).any()
     env.close()
+
+
+def test_device_prefix_curriculum_matches_reference_callback():
+    """The reference callback's recorded (dones, infos) stream (tests/golden/route_eval.json) fed to the DEVICE tracker through the env's own
+    flag buffers: stage / episode count after every step, the promotion history with its four window rates and timesteps, the final window
+    rates, and the reset window the promotions leave in the device route config."""
+    from rl_brain_trainer_amd.route_curriculum import RoutePrefixCurriculumDevice, build_prefix_stages
+
+    gold = json.loads((GOLDEN / "route_eval.json").read_text())
+    cfgd = _cfg()
+    route_q = rcfg.load_route_q(GOLDEN / "synthetic_route.json")
+    for trace in gold["callback"]:
+        n = len(trace["steps"][0]["dones"])
+        env = RouteVecEnv(kcfg.to_env_config(cfgd), rcfg.route_config_from_dict(cfgd, max_route_index=120), route_q, n, seed=2)
+        cb = RoutePrefixCurriculumDevice(stages=build_prefix_stages([20, 40, 80]), promotion_success_rate=0.75, promotion_route_ready_hit_rate=0.75,
+                                         promotion_orientation_hit_rate=0.85, promotion_max_regression_rate=0.30, window_episodes=16, min_episodes_per_stage=24)
+        cb.attach(env)
+        env.reset()
+        assert int(env.info()["route_index"].max()) <= 20          # the first prefix was applied
+        info = env.info()
+        views = [info["route_ready"], info["route_orientation_hit"], info["route_regression"]]
+        for step in trace["steps"]:
+            infos = step["infos"]
+            done = torch.tensor([(1 if d else 0) | (4 if (d and i["success"]) else 0) for d, i in zip(step["dones"], infos)], dtype=torch.uint8, device=DEV)
+            # a success flag on a not-done env must be ignored, like info["success"] of an unfinished episode
+            done |= torch.tensor([4 if (i["success"] and not d) else 0 for d, i in zip(step["dones"], infos)], dtype=torch.uint8, device=DEV)
+            for v, key in zip(views, ("route_ready", "route_orientation_hit", "route_regression")):
+                v.copy_(torch.tensor([int(i[key]) for i in infos], dtype=torch.uint8, device=DEV))
+            cb.observe(done, n)
+            st = cb.read()
+            assert (int(st.stage_index), int(st.stage_episode_count)) == (step["stage"], step["count"])
+        assert json.loads(json.dumps(cb.summary())) == trace["summary"]
+        assert env.route_cfg.reset.max_route_index == trace["summary"]["prefix_end_index"]
+        env.reset()                                                  # the device config carries the promoted window
+        idx = env.info()["route_index"]
+        assert int(idx.max()) <= trace["summary"]["prefix_end_index"]
+        cb.close()
+        env.close()

@@ -17,6 +17,7 @@ cfg = json.loads((G / "configs" / "route_curriculum_prefix120_routeobs_sequence2
 cfg["route"].pop("init_checkpoint", None)
 cfg["route"]["route_path"] = str(G / "synthetic_route.json")
 cfg["route"]["curriculum"] = {**cfg["route"].get("curriculum", {}), "prefix_stages": [20, 40, 80, 120]}
+cfg.setdefault("training", {})["checkpoint_freq"] = 10 ** 9     # the YAML's 250 k-step period is a checkpoint every 0.1 s at this speed
 cfg["route"]["sequential_gate"] = {"enabled": True, "prefixes": [20, 40, 80, 120], "full_end_index": None}
 cfg["algorithms"]["ppo"].update({"learning_rate": float(os.environ.get("KP1_ROUTE_LR", "3e-4")), "n_epochs": int(os.environ.get("KP1_ROUTE_EPOCHS", "4")), "ent_coef": float(os.environ.get("KP1_ROUTE_ENT", "1e-3")), "clip_range": float(os.environ.get("KP1_ROUTE_CLIP", "0.2"))})
 steps = int(os.environ.get("KP1_ROUTE_STEPS", "20000000"))
