@@ -371,3 +371,46 @@ def test_ppo_optimiser_step_matches_cpu_oracle():
         rm, rv = cpu(obs)
     assert torch.allclose(mean2.cpu(), rm, rtol=1e-3, atol=2e-4) and torch.allclose(value2.cpu(), rv, rtol=1e-3, atol=2e-4)
     k.close()
+
+
+@pytest.mark.parametrize("obs_dim", [56, 80])
+def test_hidden128_layerwise_path(obs_dim):
+    """net_arch 2x128 (the other width the MFMA kernels are instantiated for) runs through the layer-wise kernels: forward and
+    loss / gradient against torch, both observation widths."""
+    D, W = obs_dim, (64 if obs_dim <= 64 else 128)
+    pol = _policy(hidden=128, scale_heads=False, obs_dim=D)
+    k = MlpKernels(128, DEV, max_batch=8192, obs_dim=D)
+    k.pack(pol.flat)
+    g = torch.Generator(device=DEV).manual_seed(21)
+    total, n = 9000, 5000
+    obs = torch.zeros((total, W), device=DEV)
+    obs[:, :D] = torch.rand((total, D), device=DEV, generator=g) * 2 - 1
+    mean, value = k.mean_value(obs[:3000].contiguous())
+    with torch.no_grad():
+        m0, v0 = P.mlp_forward(pol.views, obs[:, :D].contiguous())
+    assert torch.allclose(mean, m0[:3000], rtol=1e-4, atol=2e-5) and torch.allclose(value, v0[:3000], rtol=1e-4, atol=2e-5)
+    act = m0 + torch.exp(pol.views["log_std"]) * torch.randn((total, 7), device=DEV, generator=g)
+    old_logp = P.gaussian_log_prob(act, m0 + 0.05 * torch.randn((total, 7), device=DEV, generator=g), pol.views["log_std"])
+    adv = torch.randn(total, device=DEV, generator=g) * 2 + 0.3
+    ret = v0 + torch.randn(total, device=DEV, generator=g)
+    idx = torch.randperm(total, device=DEV, generator=g)[:n]
+    grad = torch.empty(k.num_params, device=DEV)
+    stats = torch.zeros(4, device=DEV)
+    k.loss_grad(obs, idx, n, act, old_logp, adv, ret, clip_range=0.1, ent_coef=3e-4, vf_coef=0.5, inv_count=1.0 / n, grad_out=grad, stats_out=stats)
+    a = adv[idx]
+    a = (a - a.mean()) / (a.std() + 1e-8)
+    ref = P.ppo_loss_and_grad_torch(pol.flat, pol.spec, obs[idx, :D], act[idx], old_logp[idx], a, ret[idx], clip_range=0.1, ent_coef=3e-4, vf_coef=0.5)
+    off = 0
+    for name, shape in pol.spec:
+        cnt = math.prod(shape)
+        gk, gr = grad[off:off + cnt], ref[off:off + cnt]
+        scale = gr.abs().max().item() + 1e-12
+        assert (gk - gr).abs().max().item() <= 2e-4 * scale + 1e-7, name
+        off += cnt
+    # optimiser step + repack keep the layer-wise weight copies current
+    m, v = torch.zeros_like(pol.flat), torch.zeros_like(pol.flat)
+    k.adam_step(pol.flat, grad, m, v, lr=1e-3, eps=1e-5, max_grad_norm=0.5, step=1)
+    mean2, _ = k.mean_value(obs[:512].contiguous())
+    m2, _ = P.mlp_forward(pol.views, obs[:512, :D].contiguous())
+    assert torch.allclose(mean2, m2, rtol=1e-4, atol=2e-5)
+    k.close()
