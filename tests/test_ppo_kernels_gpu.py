@@ -414,3 +414,39 @@ def test_hidden128_layerwise_path(obs_dim):
     m2, _ = P.mlp_forward(pol.views, obs[:512, :D].contiguous())
     assert torch.allclose(mean2, m2, rtol=1e-4, atol=2e-5)
     k.close()
+
+
+@pytest.mark.parametrize("mode", ["raw", "given"])
+def test_loss_grad_advantage_modes(mode):
+    """normalize_advantage=False (raw advantages) and externally supplied (mean, 1/std) -- the data-parallel path's global statistics --
+    against torch autograd with the same advantages; the default per-minibatch normalisation is covered above."""
+    pol = _policy(scale_heads=False)
+    k = MlpKernels(256, DEV, max_batch=4096)
+    k.pack(pol.flat)
+    g = torch.Generator(device=DEV).manual_seed(31)
+    n = 3000
+    obs = torch.zeros((n, 64), device=DEV)
+    obs[:, :56] = torch.rand((n, 56), device=DEV, generator=g) * 2 - 1
+    with torch.no_grad():
+        m0, v0 = P.mlp_forward(pol.views, obs[:, :56].contiguous())
+    act = m0 + torch.exp(pol.views["log_std"]) * torch.randn((n, 7), device=DEV, generator=g)
+    old_logp = P.gaussian_log_prob(act, m0 + 0.05 * torch.randn((n, 7), device=DEV, generator=g), pol.views["log_std"])
+    adv = torch.randn(n, device=DEV, generator=g) * 0.7 + 0.2
+    ret = v0 + torch.randn(n, device=DEV, generator=g)
+    grad = torch.empty(k.num_params, device=DEV)
+    if mode == "raw":
+        k.loss_grad(obs, None, n, act, old_logp, adv, ret, clip_range=0.2, ent_coef=1e-3, vf_coef=0.5, inv_count=1.0 / n, grad_out=grad, stats_out=None, normalize=False)
+        a = adv
+    else:
+        stats = torch.tensor([0.37, 1.9], device=DEV)
+        k.loss_grad(obs, None, n, act, old_logp, adv, ret, clip_range=0.2, ent_coef=1e-3, vf_coef=0.5, inv_count=1.0 / n, grad_out=grad, stats_out=None, adv_stats=stats)
+        a = (adv - 0.37) * 1.9
+    ref = P.ppo_loss_and_grad_torch(pol.flat, pol.spec, obs[:, :56], act, old_logp, a, ret, clip_range=0.2, ent_coef=1e-3, vf_coef=0.5)
+    off = 0
+    for name, shape in pol.spec:
+        cnt = math.prod(shape)
+        gk, gr = grad[off:off + cnt], ref[off:off + cnt]
+        scale = gr.abs().max().item() + 1e-12
+        assert (gk - gr).abs().max().item() <= 2e-4 * scale + 1e-7, (mode, name)
+        off += cnt
+    k.close()
