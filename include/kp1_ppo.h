@@ -128,6 +128,9 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
  * (route/teacher_anchor.py:68-87) steps only the tensors its imitation loss reaches.  kp1_mlp_adam_step uses common + extra in
  * the bias corrections of those tensors. */
 #define KP1_MLP_OPT_ACTOR_EXTRA_STEPS 2
+/* KP1_MLP_OPT_STEP_COUNT: set the device-resident optimiser step count (PPO.load restores torch.optim.Adam's state, whose per-tensor
+ * `step` feeds the bias corrections); kp1_mlp_loss_grad increments it, kp1_mlp_adam_step(step = 0) reads it. */
+#define KP1_MLP_OPT_STEP_COUNT 3
 int kp1_mlp_set_option(kp1_mlp* m, int32_t option, int32_t value);
 
 /* clip_grad_norm_(max_norm) + Adam(beta 0.9/0.999, eps) step on the flat vectors; the same pass repacks the kernel-format

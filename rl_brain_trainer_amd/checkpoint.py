@@ -82,11 +82,12 @@ def _torch_bytes(obj: Any) -> bytes:
 def optimizer_state_dict(ppo) -> dict[str, Any]:
     """torch.optim.Adam.state_dict() of the flat Adam moments, one entry per SB3 parameter (policy.parameters() order)."""
     state, off = {}, 0
-    step = torch.tensor(float(ppo.adam_t))
+    extra = int(getattr(ppo, "actor_extra_steps", 0))   # teacher-anchor steps reach only the actor tensors (torch counts per tensor)
     for i, (name, shape) in enumerate(ppo.policy.spec):
         n = 1
         for d in shape:
             n *= d
+        step = torch.tensor(float(ppo.adam_t + (extra if name.startswith(("mlp_extractor.policy_net", "action_net")) else 0)))
         state[i] = {"step": step.clone(), "exp_avg": ppo.adam_m[off:off + n].view(shape).detach().cpu().clone(),
                     "exp_avg_sq": ppo.adam_v[off:off + n].view(shape).detach().cpu().clone()}
         off += n
@@ -123,6 +124,18 @@ def load_policy_state_dict(path: str | Path) -> dict[str, torch.Tensor]:
             raw = z.read("policy.pth")
         return torch.load(io.BytesIO(raw), map_location="cpu", weights_only=True)
     return torch.load(path, map_location="cpu", weights_only=True)
+
+
+def load_optimizer_state_dict(path: str | Path) -> dict[str, Any] | None:
+    """policy.optimizer.pth of an SB3 zip (torch.optim.Adam.state_dict()), safe loader only; None when the member is missing."""
+    path = Path(path)
+    if path.suffix != ".zip":
+        path = path.with_name(path.name + ".zip")
+    with zipfile.ZipFile(path) as z:
+        if "policy.optimizer.pth" not in z.namelist():
+            return None
+        raw = z.read("policy.optimizer.pth")
+    return torch.load(io.BytesIO(raw), map_location="cpu", weights_only=True)
 
 
 def load_data(path: str | Path) -> dict[str, Any]:

@@ -1264,6 +1264,12 @@ int kp1_mlp_set_option(kp1_mlp* m, int32_t option, int32_t value) {
     }
     return KP1_OK;
   }
+  if (option == KP1_MLP_OPT_STEP_COUNT) {   // optimiser steps taken so far (resuming from a checkpoint's Adam state)
+    if (value < 0) return fail(KP1_ERR_INVALID, "step count must be >= 0");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemcpy(m->step_dev, &value, sizeof(int), hipMemcpyHostToDevice));
+    return KP1_OK;
+  }
   if (option == KP1_MLP_OPT_ACTOR_EXTRA_STEPS) {
     if (value < 0) return fail(KP1_ERR_INVALID, "actor extra steps must be >= 0");
     HIP_TRY(hipSetDevice(m->device));

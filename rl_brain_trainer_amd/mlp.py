@@ -55,6 +55,12 @@ class MlpKernels:
         """Adam steps the actor tensors have taken beyond the common count (teacher-anchor side updates, teacher_anchor.py)."""
         native.check(self.L.kp1_mlp_set_option(self._h, self.OPT_ACTOR_EXTRA_STEPS, int(steps)))
 
+    OPT_STEP_COUNT = 3
+
+    def set_step_count(self, steps: int) -> None:
+        """Device-resident optimiser step count (restoring a checkpoint's Adam state)."""
+        native.check(self.L.kp1_mlp_set_option(self._h, self.OPT_STEP_COUNT, int(steps)))
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 

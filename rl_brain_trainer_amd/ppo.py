@@ -188,6 +188,8 @@ class PPO:
         self.adam_m = torch.zeros_like(self.policy.flat)
         self.adam_v = torch.zeros_like(self.policy.flat)
         self.adam_t = 0
+        self.actor_extra_steps = 0     # optimiser steps only the actor tensors took (teacher-anchor side updates)
+        self._epoch_warm = False       # one eager epoch has run (kernel attributes set, code objects loaded) before the epoch graph is captured
         self.curriculum = curriculum
         if curriculum is not None:
             curriculum.attach(env)
@@ -235,6 +237,43 @@ class PPO:
         if self.use_graphs:
             self.noise_all = torch.zeros((T, N, ACT_DIM), dtype=torch.float32, device=dev)
             self.perm = torch.zeros(T * N, dtype=torch.int64, device=dev)
+
+    # ------------------------------------------------------------------ PPO.load
+    def load_checkpoint(self, path: str, *, restore_optimizer: bool = True, restore_timesteps: bool = False) -> dict[str, Any]:
+        """``PPO.load(path, env=...)`` for an SB3 zip (the reference's resume paths, train_workspace_expansion.py:187-197,
+        train_route_curriculum.py:129-139): policy weights, and the Adam state of ``policy.optimizer.pth`` when present -- first / second
+        moments per tensor and torch's per-tensor step counts (a common count, plus the extra steps of the actor tensors when a
+        teacher-anchor run wrote the file).  Returns what was restored."""
+        from . import checkpoint
+
+        self.policy.load_state_dict(checkpoint.load_policy_state_dict(path))
+        restored: dict[str, Any] = {"policy": True, "optimizer": False}
+        opt = checkpoint.load_optimizer_state_dict(path) if restore_optimizer else None
+        if opt and opt.get("state"):
+            steps, off = [], 0
+            for i, (name, shape) in enumerate(self.policy.spec):
+                n = math.prod(shape)
+                st = opt["state"].get(i)
+                if st is None or tuple(st["exp_avg"].shape) != tuple(shape):
+                    raise ValueError(f"optimizer state of parameter {i} ({name}) does not match the policy")
+                self.adam_m[off:off + n].copy_(st["exp_avg"].to(self.device, torch.float32).reshape(-1))
+                self.adam_v[off:off + n].copy_(st["exp_avg_sq"].to(self.device, torch.float32).reshape(-1))
+                steps.append((name, int(float(st["step"]))))
+                off += n
+            actor = [s_ for n_, s_ in steps if n_.startswith(("mlp_extractor.policy_net", "action_net"))]
+            rest = [s_ for n_, s_ in steps if not n_.startswith(("mlp_extractor.policy_net", "action_net"))]
+            if len(set(actor)) != 1 or len(set(rest)) != 1 or actor[0] < rest[0]:
+                raise ValueError(f"unsupported per-tensor Adam step pattern {steps}")
+            self.adam_t, self.actor_extra_steps = rest[0], actor[0] - rest[0]
+            restored.update({"optimizer": True, "adam_steps": self.adam_t, "actor_extra_steps": self.actor_extra_steps})
+        if self._mlp is not None:
+            self._mlp.pack(self.policy.flat)
+            self._mlp.set_step_count(self.adam_t)
+            self._mlp.set_actor_extra_steps(self.actor_extra_steps)
+        if restore_timesteps:
+            self.num_timesteps = int(checkpoint.load_data(path).get("num_timesteps", 0))
+            restored["num_timesteps"] = self.num_timesteps
+        return restored
 
     # ------------------------------------------------------------------ policy evaluation
     def _forward(self, obs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
@@ -402,7 +441,8 @@ class PPO:
                 torch.randperm(total, device=self.device, generator=self.gen, out=self.perm)
                 if self._epoch_graph is None:
                     # one eager epoch first (warm-up + it is a real epoch), then capture for the following ones
-                    if _epoch == 0 and self.adam_t == 0:
+                    if not self._epoch_warm:
+                        self._epoch_warm = True
                         mb_stats = self._epoch_adv_stats(adv, self.perm, total, local_bs)
                         for i, start in enumerate(range(0, total, local_bs)):
                             self._hip_minibatch_step(obs, self.perm[start:start + local_bs], act, old_logp, adv, ret, device_step=True,

@@ -73,6 +73,7 @@ class RouteTeacherAnchor:
         if actions.size == 0:
             raise ValueError(f"No teacher-anchor samples left after max_route_index={self.config.max_route_index}")
         obs = {key.removeprefix("obs__"): np.asarray(payload[key], dtype=np.float32)[keep] for key in payload.files if key.startswith("obs__")}
+        self.actor_extra_steps = int(getattr(ppo, "actor_extra_steps", 0))   # a resumed teacher-anchored run carries its count
         self._obs = torch.as_tensor(flatten_observation(obs, ppo.obs_dim), device=ppo.device)
         self._actions = torch.as_tensor(actions, device=ppo.device)
 
@@ -121,6 +122,7 @@ class RouteTeacherAnchor:
                 denom = (v.sqrt() / math.sqrt(bc2)).add_(cfg.adam_eps)
                 ppo.policy.flat[sl].addcdiv_(m, denom, value=-cfg.learning_rate / bc1)
         self.actor_extra_steps += 1
+        ppo.actor_extra_steps = self.actor_extra_steps
         if ppo._mlp is not None:
             ppo._mlp.pack(ppo.policy.flat)
             ppo._mlp.set_actor_extra_steps(self.actor_extra_steps)

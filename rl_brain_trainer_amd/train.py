@@ -150,10 +150,7 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
     ppo = PPO(env, pcfg, curriculum=curriculum, dist=Dist(), backend="hip" if args.hidden in (128, 256) else "torch")
     resume = args.resume_from or ws.get("init_approach_checkpoint", "")
     if resume and Path(resume).exists():
-        sd = checkpoint.load_policy_state_dict(resume)
-        ppo.policy.load_state_dict(sd)
-        if ppo._mlp is not None:
-            ppo._mlp.pack(ppo.policy.flat)
+        ppo.load_checkpoint(resume)   # PPO.load(resume, env=vec_env): weights + Adam state
         if rank == 0:
             print(f"Resuming workspace expansion from {resume}")
 

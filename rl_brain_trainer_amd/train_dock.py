@@ -89,9 +89,7 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
     pcfg = PPOConfig.from_algo_kwargs(model_kwargs, n_steps=args.n_steps, batch_size=batch, hidden=args.hidden)
     ppo = PPO(env, pcfg, dist=Dist(), backend="hip" if args.hidden in (128, 256) else "torch")
     if args.resume_from and Path(args.resume_from).exists():
-        ppo.policy.load_state_dict(checkpoint.load_policy_state_dict(args.resume_from))
-        if ppo._mlp is not None:
-            ppo._mlp.pack(ppo.policy.flat)
+        ppo.load_checkpoint(args.resume_from)   # PPO.load(resume, env=vec_env): weights + Adam state
         if rank == 0:
             print(f"Resuming dock policy from {args.resume_from}")
 

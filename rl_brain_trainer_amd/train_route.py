@@ -92,9 +92,8 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
     on_device = isinstance(curriculum, RoutePrefixCurriculumDevice)
     ppo = PPO(env, pcfg, curriculum=curriculum if on_device else None, dist=Dist(), backend="hip" if hip else "torch")
     if init_checkpoint:
-        ppo.policy.load_state_dict(checkpoint.load_policy_state_dict(init_checkpoint))   # PPO.load(..., env=vec_env); the YAML's learning rate wins
-        if ppo._mlp is not None:
-            ppo._mlp.pack(ppo.policy.flat)
+        # PPO.load(..., env=vec_env) + learn(reset_num_timesteps=False): weights, Adam state, step clock; the YAML's learning rate wins
+        ppo.load_checkpoint(init_checkpoint, restore_timesteps=True)
         print(f"Resuming route policy from {init_checkpoint}")
 
     if not on_device:

@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import io
 import json
+import math
 import zipfile
 
 import numpy as np
@@ -175,3 +176,47 @@ def test_ppo_learns_stage0_reaching():
     r = finals[0][0]
     assert np.mean(r[-3:]) > np.mean(r[:3]) + 0.002, r
     assert all(np.isfinite(r))
+
+
+def test_resume_restores_adam_state(tmp_path):
+    """PPO.load for a resumed run (train_workspace_expansion.py:187-197, train_route_curriculum.py:129-139): after load_checkpoint the
+    Adam moments, the common step count, the actor tensors' extra step count and the device-resident counter are those of the saved
+    model, so the next optimiser step is bitwise the one the saved model would have taken."""
+    cfg = load_golden_config("workspace_expansion_bigtrain")
+
+    def make(seed):
+        env = ArmKinematicVecEnv(cfg, 128, seed=806)
+        env.set_curriculum_stage(5)
+        return env, P.PPO(env, P.PPOConfig(n_steps=8, batch_size=512, n_epochs=2, hidden=256, learning_rate=1e-3, seed=seed), use_graphs=True)
+
+    env_a, a = make(5)
+    for _ in range(2):
+        a.collect_rollouts()
+        a.train()
+    a.actor_extra_steps = 3                      # as after three teacher-anchor steps
+    a._mlp.set_actor_extra_steps(3)
+    path = checkpoint.save(tmp_path / "model", a, cfg)
+    env_b, b = make(99)
+    restored = b.load_checkpoint(str(path), restore_timesteps=True)
+    assert restored["optimizer"] and restored["adam_steps"] == a.adam_t == 8 and restored["actor_extra_steps"] == 3
+    assert b.num_timesteps == a.num_timesteps
+    assert torch.equal(b.policy.flat, a.policy.flat) and torch.equal(b.adam_m, a.adam_m) and torch.equal(b.adam_v, a.adam_v)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    grad = 1e-3 * torch.randn(a.policy.flat.numel(), device="cuda", generator=g)
+    for ppo in (a, b):   # device-resident step count (what the graph-replayed update uses): both must read 8 (+3 for the actor tensors)
+        ppo._mlp.adam_step(ppo.policy.flat, grad.clone(), ppo.adam_m, ppo.adam_v, lr=1e-3, eps=1e-5, max_grad_norm=0.5, step=0)
+    assert torch.equal(b.policy.flat, a.policy.flat) and torch.equal(b.adam_m, a.adam_m)
+    # and the host-step form agrees with torch's formula for step 9 on a non-actor tensor (log_std) and step 12 on an actor tensor
+    env_c, c = make(7)
+    c.load_checkpoint(str(path))
+    before = c.policy.flat.clone()
+    m0, v0 = c.adam_m.clone(), c.adam_v.clone()
+    c._mlp.adam_step(c.policy.flat, grad.clone(), c.adam_m, c.adam_v, lr=1e-3, eps=1e-5, max_grad_norm=0.0, step=c.adam_t + 1)
+    for idx, step in ((0, 9), (7 + 5, 12)):     # element 0 = log_std[0]; element 12 = policy_net.0.weight[0, 5]
+        gi = grad[idx].item()
+        mi = 0.9 * m0[idx].item() + 0.1 * gi
+        vi = 0.999 * v0[idx].item() + 0.001 * gi * gi
+        expect = before[idx].item() - 1e-3 / (1 - 0.9 ** step) * mi / (math.sqrt(vi) / math.sqrt(1 - 0.999 ** step) + 1e-5)
+        assert abs(c.policy.flat[idx].item() - expect) <= 2e-6 * max(1.0, abs(expect)), (idx, step)
+    for e in (env_a, env_b, env_c):
+        e.close()
