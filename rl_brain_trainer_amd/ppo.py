@@ -239,11 +239,16 @@ class PPO:
             self.perm = torch.zeros(T * N, dtype=torch.int64, device=dev)
 
     # ------------------------------------------------------------------ PPO.load
-    def load_checkpoint(self, path: str, *, restore_optimizer: bool = True, restore_timesteps: bool = False) -> dict[str, Any]:
+    def load_checkpoint(self, path: str, *, restore_optimizer: bool = True, restore_timesteps: bool = False,
+                        restore_hyperparameters: bool = False) -> dict[str, Any]:
         """``PPO.load(path, env=...)`` for an SB3 zip (the reference's resume paths, train_workspace_expansion.py:187-197,
         train_route_curriculum.py:129-139): policy weights, and the Adam state of ``policy.optimizer.pth`` when present -- first / second
         moments per tensor and torch's per-tensor step counts (a common count, plus the extra steps of the actor tensors when a
-        teacher-anchor run wrote the file).  Returns what was restored."""
+        teacher-anchor run wrote the file).  ``restore_hyperparameters``: a loaded SB3 model keeps the algorithm constants it was saved
+        with (gamma, gae_lambda, ent_coef, vf_coef, max_grad_norm, n_epochs, normalize_advantage, and clip_range when the zip stores it
+        as a plain value); the trainers then re-apply only the YAML's learning rate.  The rollout geometry (n_envs, n_steps, minibatch)
+        stays the engine's: it is sized for the GPU, not for the 12-16 CPU envs a reference checkpoint was collected with.  Must be called
+        before the first update (the constants are baked into the captured graphs).  Returns what was restored."""
         from . import checkpoint
 
         self.policy.load_state_dict(checkpoint.load_policy_state_dict(path))
@@ -270,9 +275,26 @@ class PPO:
             self._mlp.pack(self.policy.flat)
             self._mlp.set_step_count(self.adam_t)
             self._mlp.set_actor_extra_steps(self.actor_extra_steps)
-        if restore_timesteps:
-            self.num_timesteps = int(checkpoint.load_data(path).get("num_timesteps", 0))
-            restored["num_timesteps"] = self.num_timesteps
+        if restore_timesteps or restore_hyperparameters:
+            data = checkpoint.load_data(path)
+            if restore_timesteps:
+                self.num_timesteps = int(data.get("num_timesteps", 0))
+                restored["num_timesteps"] = self.num_timesteps
+            if restore_hyperparameters:
+                if self._epoch_graph is not None or self.adam_t != restored.get("adam_steps", self.adam_t):
+                    raise RuntimeError("restore_hyperparameters must happen before the first update")
+                taken = {}
+                for key, cast in (("gamma", float), ("gae_lambda", float), ("ent_coef", float), ("vf_coef", float), ("max_grad_norm", float),
+                                  ("n_epochs", int), ("normalize_advantage", bool)):
+                    v = data.get(key)
+                    if isinstance(v, (int, float, bool)) and not (isinstance(v, bool) and cast is not bool):
+                        setattr(self.cfg, key, cast(v))
+                        taken[key] = cast(v)
+                clip = data.get("clip_range")
+                if isinstance(clip, dict) and isinstance(clip.get("value"), (int, float)):   # this engine's writer; SB3 pickles the schedule
+                    self.cfg.clip_range = float(clip["value"])
+                    taken["clip_range"] = self.cfg.clip_range
+                restored["hyperparameters"] = taken
         return restored
 
     # ------------------------------------------------------------------ policy evaluation

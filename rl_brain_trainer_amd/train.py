@@ -150,7 +150,8 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
     ppo = PPO(env, pcfg, curriculum=curriculum, dist=Dist(), backend="hip" if args.hidden in (128, 256) else "torch")
     resume = args.resume_from or ws.get("init_approach_checkpoint", "")
     if resume and Path(resume).exists():
-        ppo.load_checkpoint(resume)   # PPO.load(resume, env=vec_env): weights + Adam state
+        # PPO.load(resume, env=vec_env): weights, Adam state and the saved algorithm constants; the YAML's learning rate is re-applied
+        ppo.load_checkpoint(resume, restore_hyperparameters=True)
         if rank == 0:
             print(f"Resuming workspace expansion from {resume}")
 

@@ -89,7 +89,8 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
     pcfg = PPOConfig.from_algo_kwargs(model_kwargs, n_steps=args.n_steps, batch_size=batch, hidden=args.hidden)
     ppo = PPO(env, pcfg, dist=Dist(), backend="hip" if args.hidden in (128, 256) else "torch")
     if args.resume_from and Path(args.resume_from).exists():
-        ppo.load_checkpoint(args.resume_from)   # PPO.load(resume, env=vec_env): weights + Adam state
+        # PPO.load(resume, env=vec_env) + learn(reset_num_timesteps=False) (train_dock_policy.py:89-102)
+        ppo.load_checkpoint(args.resume_from, restore_timesteps=True, restore_hyperparameters=True)
         if rank == 0:
             print(f"Resuming dock policy from {args.resume_from}")
 

@@ -93,7 +93,7 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
     ppo = PPO(env, pcfg, curriculum=curriculum if on_device else None, dist=Dist(), backend="hip" if hip else "torch")
     if init_checkpoint:
         # PPO.load(..., env=vec_env) + learn(reset_num_timesteps=False): weights, Adam state, step clock; the YAML's learning rate wins
-        ppo.load_checkpoint(init_checkpoint, restore_timesteps=True)
+        ppo.load_checkpoint(init_checkpoint, restore_timesteps=True, restore_hyperparameters=True)
         print(f"Resuming route policy from {init_checkpoint}")
 
     if not on_device:

@@ -197,8 +197,11 @@ def test_resume_restores_adam_state(tmp_path):
     a._mlp.set_actor_extra_steps(3)
     path = checkpoint.save(tmp_path / "model", a, cfg)
     env_b, b = make(99)
-    restored = b.load_checkpoint(str(path), restore_timesteps=True)
+    b.cfg.gamma, b.cfg.ent_coef, b.cfg.clip_range, b.cfg.n_epochs = 0.9, 0.123, 0.3, 5
+    restored = b.load_checkpoint(str(path), restore_timesteps=True, restore_hyperparameters=True)
     assert restored["optimizer"] and restored["adam_steps"] == a.adam_t == 8 and restored["actor_extra_steps"] == 3
+    assert (b.cfg.gamma, b.cfg.ent_coef, b.cfg.clip_range, b.cfg.n_epochs) == (a.cfg.gamma, a.cfg.ent_coef, a.cfg.clip_range, a.cfg.n_epochs)
+    assert b.cfg.seed == 99 and set(restored["hyperparameters"]) >= {"gamma", "gae_lambda", "ent_coef", "vf_coef", "max_grad_norm", "n_epochs", "clip_range"}
     assert b.num_timesteps == a.num_timesteps
     assert torch.equal(b.policy.flat, a.policy.flat) and torch.equal(b.adam_m, a.adam_m) and torch.equal(b.adam_v, a.adam_v)
     g = torch.Generator(device="cuda").manual_seed(3)

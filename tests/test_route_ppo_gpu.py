@@ -196,6 +196,15 @@ def test_train_route_cli(tmp_path):
     for name in ("model_latest.zip", "curriculum_history.json", "training_summary.json", "route_eval_sequential/route_eval_sequential_summary.json",
                  "route_gate/route_gate_summary.json", "route_gate/full_12/route_eval_sequential_summary.json", "checkpoints/model_4096_steps.zip"):
         assert (out / name).exists(), name
+    # resumed run: PPO.load(init_checkpoint) + learn(reset_num_timesteps=False) -- the step clock and the Adam state carry on
+    out2 = tmp_path / "run2"
+    s2 = train_route.main(["--config", str(cfg_path), "--run-id", "t2", "--output-dir", str(out2), "--total-timesteps", "4096", "--n-envs", "128", "--n-steps", "16",
+                           "--batch-size", "512", "--seed", "4", "--init-checkpoint", str(out / "model_latest.zip")])
+    assert s2["init_checkpoint"] == str(out / "model_latest.zip") and s2["num_timesteps"] == summary["num_timesteps"] + 4096
+    from rl_brain_trainer_amd import checkpoint as ck
+    o1, o2 = ck.load_optimizer_state_dict(out / "model_latest.zip"), ck.load_optimizer_state_dict(out2 / "model_latest.zip")
+    assert float(o2["state"][0]["step"]) > float(o1["state"][0]["step"]) > 0
+    assert float(o2["state"][1]["step"]) - float(o2["state"][0]["step"]) > float(o1["state"][1]["step"]) - float(o1["state"][0]["step"]) > 0   # anchor steps
     # the zip reloads as an 80-input policy
     pol = P.InferencePolicy.load(str(out / "model_latest.zip"))
     assert pol.obs_dim == 80
