@@ -53,6 +53,18 @@ def flatten_observation(obs: dict[str, np.ndarray], obs_dim: int) -> np.ndarray:
     return flat
 
 
+def load_anchor_dataset(path: str | Path, max_route_index: int, obs_dim: int) -> tuple[np.ndarray, np.ndarray]:
+    """``teacher_route_anchor_dataset.npz`` (collect_route_teacher_rollout) -> (flat observations [M, obs_dim], actions [M, 7]) of the
+    samples whose waypoint lies inside the protected prefix."""
+    with np.load(Path(path), allow_pickle=False) as data:
+        inside = np.asarray(data["route_index"], dtype=np.int32) <= max_route_index
+        actions = np.asarray(data["actions"], dtype=np.float32)[inside]
+        keyed = {name[len("obs__"):]: np.asarray(data[name], dtype=np.float32)[inside] for name in data.files if name.startswith("obs__")}
+    if not len(actions):
+        raise ValueError(f"No teacher-anchor samples left after max_route_index={max_route_index}")
+    return flatten_observation(keyed, obs_dim), actions
+
+
 class RouteTeacherAnchor:
     def __init__(self, config: TeacherAnchorConfig) -> None:
         if not config.dataset_path:
@@ -66,29 +78,25 @@ class RouteTeacherAnchor:
         self.last_loss = 0.0
 
     def on_training_start(self, ppo) -> None:
-        payload = np.load(Path(self.config.dataset_path), allow_pickle=False)
-        route_index = np.asarray(payload["route_index"], dtype=np.int32)
-        keep = route_index <= int(self.config.max_route_index)
-        actions = np.asarray(payload["actions"], dtype=np.float32)[keep]
-        if actions.size == 0:
-            raise ValueError(f"No teacher-anchor samples left after max_route_index={self.config.max_route_index}")
-        obs = {key.removeprefix("obs__"): np.asarray(payload[key], dtype=np.float32)[keep] for key in payload.files if key.startswith("obs__")}
+        """Put the protected-prefix part of the recorded dataset on the device, flattened to the policy's input rows."""
+        flat_obs, actions = load_anchor_dataset(self.config.dataset_path, int(self.config.max_route_index), ppo.obs_dim)
         self.actor_extra_steps = int(getattr(ppo, "actor_extra_steps", 0))   # a resumed teacher-anchored run carries its count
-        self._obs = torch.as_tensor(flatten_observation(obs, ppo.obs_dim), device=ppo.device)
+        self._obs = torch.as_tensor(flat_obs, device=ppo.device)
         self._actions = torch.as_tensor(actions, device=ppo.device)
 
     def sample_indices(self) -> np.ndarray:
-        assert self._actions is not None
-        batch_size = min(int(self.config.batch_size), len(self._actions))
-        return self._rng.integers(0, len(self._actions), size=batch_size)
+        """the next batch's row indices: ``rng.integers(0, M, size=min(batch_size, M))`` on the callback's default_rng(0) stream"""
+        rows = int(self._actions.shape[0])
+        return self._rng.integers(0, rows, size=min(int(self.config.batch_size), rows))
 
     def on_rollout_end(self, ppo) -> None:
         self._rollout_count += 1
-        if self._rollout_count % max(int(self.config.every_rollouts), 1) != 0:
+        period = max(int(self.config.every_rollouts), 1)
+        if self._rollout_count % period:
             return
-        for _ in range(max(int(self.config.gradient_steps), 1)):
-            idx = torch.as_tensor(self.sample_indices(), device=ppo.device)
-            self.last_loss = self.gradient_step(ppo, self._obs.index_select(0, idx), self._actions.index_select(0, idx))
+        for _step in range(max(int(self.config.gradient_steps), 1)):
+            pick = torch.as_tensor(self.sample_indices(), device=ppo.device)
+            self.last_loss = self.gradient_step(ppo, self._obs.index_select(0, pick), self._actions.index_select(0, pick))
 
     def gradient_step(self, ppo, obs: torch.Tensor, teacher_actions: torch.Tensor) -> float:
         """One clip_grad_norm_(0.5) + Adam step of the imitation loss on the actor tensors of ``ppo`` (in place)."""
@@ -129,7 +137,9 @@ class RouteTeacherAnchor:
         return float(loss.detach().item())
 
     def summary(self) -> dict[str, Any]:
-        c = self.config
-        return {"enabled": True, "dataset_path": c.dataset_path, "loss_weight": float(c.loss_weight), "batch_size": int(c.batch_size),
-                "gradient_steps": int(c.gradient_steps), "every_rollouts": int(c.every_rollouts), "max_route_index": int(c.max_route_index),
-                "sample_count": 0 if self._actions is None else int(len(self._actions))}
+        import dataclasses
+
+        out = {f.name: getattr(self.config, f.name) for f in dataclasses.fields(self.config)}   # the config as the reference reports it
+        out["enabled"] = True
+        out["sample_count"] = int(self._actions.shape[0]) if self._actions is not None else 0
+        return out
