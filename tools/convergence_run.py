@@ -32,7 +32,8 @@ cur = cfg_dict["env"]["curriculum"]
 N = 4096
 env = ArmKinematicVecEnv(env_cfg, N, seed=806)
 curriculum = PointCurriculum(success_rate_threshold=float(cur.get("success_rate_threshold", 0.8)), window_episodes=int(cur.get("window_episodes", 20)),
-                             min_episodes_per_stage=int(cur.get("min_episodes_per_stage", 30)), max_stage_index=min(5, env_cfg.n_stages - 1), initial_stage_index=0,
+                             min_episodes_per_stage=int(cur.get("min_episodes_per_stage", 30)), max_stage_index=min(5, env_cfg.n_stages - 1),
+                             initial_stage_index=int(os.environ.get("KP1_START_STAGE", "0")),
                              device=0)
 epochs = int(os.environ.get("KP1_EPOCHS", "8"))
 clip = float(os.environ.get("KP1_CLIP", "0.1"))
@@ -40,10 +41,13 @@ ent = float(os.environ.get("KP1_ENT", "3e-4"))
 batch = int(os.environ.get("KP1_BATCH", "8192"))
 ppo = PPO(env, PPOConfig(n_steps=128, batch_size=batch, n_epochs=epochs, hidden=256, learning_rate=lr, gamma=0.995, gae_lambda=0.95, clip_range=clip, ent_coef=ent,
                          seed=806), curriculum=curriculum, backend="hip")
+if os.environ.get("KP1_INIT"):     # fine-tuning schedule: continue from a checkpoint of an earlier phase (weights + Adam state; this phase's constants)
+    print("resumed:", ppo.load_checkpoint(os.environ["KP1_INIT"]), flush=True)
+start_steps = ppo.num_timesteps
 t0 = time.time()
 log = []
 it = 0
-while ppo.num_timesteps < total:
+while ppo.num_timesteps - start_steps < total:
     ppo.collect_rollouts()
     ppo.train()
     it += 1
@@ -68,6 +72,10 @@ summary = {"hyper": {"epochs": epochs, "clip": clip, "ent_coef": ent, "batch": b
            "final_stage": int(curriculum.read().stage_index), "curriculum": curriculum.summary(),
            "stage_metrics": {k: {m: v[m] for m in ("success_rate", "mean_final_position_error", "mean_final_orientation_error")} for k, v in res["stage_metrics"].items()},
            "log": log}
+if os.environ.get("KP1_SAVE"):
+    from rl_brain_trainer_amd import checkpoint
+
+    print("saved", checkpoint.save(os.environ["KP1_SAVE"], ppo, env_cfg), flush=True)
 os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
 json.dump(summary, open(out, "w"), indent=1)
 print(json.dumps({k: summary[k] for k in ("total_timesteps", "wall_seconds", "final_stage", "stage_metrics")}, indent=1))
