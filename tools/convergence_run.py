@@ -3,7 +3,15 @@
     python tools/convergence_run.py [total_timesteps] [learning_rate] [out_json]
 
 BASELINE.md quotes 0.93 success / 2.89 mm at stage 5 for the reference after its multi-stage fine-tuning schedule; this script is
-the engine's own end-to-end evidence that rollout, curriculum tracker, fused MFMA update and evaluator learn the task."""
+the engine's own end-to-end evidence that rollout, curriculum tracker, fused MFMA update and evaluator learn the task.
+
+Env knobs: KP1_CONFIG (approach_default | bigtrain), KP1_EPOCHS, KP1_CLIP, KP1_ENT, KP1_BATCH, KP1_START_STAGE, KP1_SAVE (write the final
+model as an SB3 zip), KP1_INIT (resume from one: weights + Adam state).  The two-phase schedule of DESIGN.md section 5
+(profiles/r01_learning_finetune_bigtrain_*.json):
+
+    KP1_CONFIG=approach_default KP1_EPOCHS=4 KP1_CLIP=0.2 KP1_ENT=0 KP1_SAVE=/tmp/phase1 python tools/convergence_run.py 1e8 3e-4 p1.json
+    KP1_INIT=/tmp/phase1.zip KP1_START_STAGE=5 KP1_EPOCHS=4 KP1_CLIP=0.1 KP1_ENT=1e-4 python tools/convergence_run.py 1.2e10 3e-5 p2.json
+"""
 import json
 import os
 import sys
