@@ -495,6 +495,17 @@ int kp1_rng_set(kp1_env* env, const kp1_rng_state* states_host /* [N] */);
 /* stand-alone batched kinematics (fk_interface.py:21-22, pose_utils.py:21-26): q real[n][7] -> pose6 real[n][6] */
 int kp1_fk_pose6(int32_t device, int32_t real_type, const void* q_dev, void* pose6_dev, int64_t n, void* stream);
 
+/* pose_error_components (KP1/kinematics/pose_utils.py:21-30, wrap_to_pi :11-12) through the device function the step and reset
+ * kernels call: curr / goal real[n][6] -> pos_err real[n][3], ori_err real[n][3] (each component wrapped to [-pi, pi)),
+ * norms real[n][2] = (|pos_err|, |ori_err|).  Any output may be NULL. */
+int kp1_pose_error(int32_t device, int32_t real_type, const void* curr_dev, const void* goal_dev, void* pos_err_dev, void* ori_err_dev,
+                   void* norms_dev, int64_t n, void* stream);
+/* joint utilities of KP1/kinematics/joint_limits.py through the device functions of the hot path: q, dq real[n][7] ->
+ * clipped = clip_joint_configuration(q) :133-135, margin = joint_limit_margin(clipped) :166-174, q_norm = normalize_joint_positions(q)
+ * :153-158, dq_norm = normalize_joint_deltas(dq) :161-163, all real[n][7].  Limits come from `cfg->joints`.  Outputs may be NULL. */
+int kp1_joint_utils(int32_t device, int32_t real_type, const kp1_config* cfg, const void* q_dev, const void* dq_dev, void* clipped_dev,
+                    void* margin_dev, void* q_norm_dev, void* dq_norm_dev, int64_t n, void* stream);
+
 /* numpy-compatible seeding helper: PCG64 state of np.random.default_rng(seed) (host side) */
 int kp1_rng_seed_state(uint64_t seed, kp1_rng_state* out);
 

@@ -498,6 +498,27 @@ __device__ __forceinline__ R dock_reward(const typename DevCfg<R>::DockReward& _
   return r;
 }
 
+// ---- joint utilities (KP1/kinematics/joint_limits.py) ---------------------------------------
+// One joint at a time; the step kernel, the observation builder and the kp1_joint_utils entry point (device-side check of the
+// reference's joint_utils fixture) all go through these, so what the fixture pins is what the hot path runs.
+template <typename R>
+__device__ __forceinline__ R joint_span(R lo, R hi) { return kp_max<R>(hi - lo, (R)1e-9); }
+// clip_joint_configuration :133-135
+template <typename R>
+__device__ __forceinline__ R joint_clip(R q, R lo, R hi) { return kp_clip<R>(q, lo, hi); }
+// joint_limit_margin :166-174
+template <typename R>
+__device__ __forceinline__ R joint_limit_margin(R q, R lo, R hi) {
+  const R span = joint_span<R>(lo, hi);
+  return kp_clip<R>((R)2 * kp_min<R>((q - lo) / span, (hi - q) / span), (R)0, (R)1);
+}
+// normalize_joint_positions :153-158
+template <typename R>
+__device__ __forceinline__ R joint_normalize_q(R q, R lo, R hi) { return kp_clip<R>((R)2 * ((q - lo) / joint_span<R>(lo, hi)) - (R)1, (R)-1, (R)1); }
+// normalize_joint_deltas :161-163
+template <typename R>
+__device__ __forceinline__ R joint_normalize_dq(R dq, R dlim) { return kp_clip<R>(dq / kp_max<R>(dlim, (R)1e-9), (R)-1, (R)1); }
+
 // KP1/envs/observation_builder.py:29-94 -> one row of 56 floats in SB3 key order (kp1.h KP1_OBS_*)
 template <typename R>
 __device__ __forceinline__ void build_observation(const DevCfg<R>& __restrict__ c, int mode, const R* q, const R* dq, const R* prev_action,
@@ -506,12 +527,10 @@ __device__ __forceinline__ void build_observation(const DevCfg<R>& __restrict__ 
   for (int i = 0; i < KP1_OBS_DIM; ++i) o[i] = 0.0f;
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {
-    R span = kp_max<R>(c.upper[i] - c.lower[i], (R)1e-9);
-    o[KP1_OBS_Q + i] = (float)kp_clip<R>((R)2 * ((q[i] - c.lower[i]) / span) - (R)1, (R)-1, (R)1);
-    o[KP1_OBS_DQ + i] = (float)kp_clip<R>(dq[i] / kp_max<R>(c.dlim[i], (R)1e-9), (R)-1, (R)1);
+    o[KP1_OBS_Q + i] = (float)joint_normalize_q<R>(q[i], c.lower[i], c.upper[i]);
+    o[KP1_OBS_DQ + i] = (float)joint_normalize_dq<R>(dq[i], c.dlim[i]);
     o[KP1_OBS_PREV_ACTION + i] = (float)kp_clip<R>(prev_action[i], (R)-1, (R)1);
-    R left = (q[i] - c.lower[i]) / span, right = (c.upper[i] - q[i]) / span;
-    o[KP1_OBS_JOINT_LIMIT_MARGIN + i] = (float)kp_clip<R>((R)2 * kp_min<R>(left, right), (R)0, (R)1);
+    o[KP1_OBS_JOINT_LIMIT_MARGIN + i] = (float)joint_limit_margin<R>(q[i], c.lower[i], c.upper[i]);
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {

@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
         cmd = kp_clip<R>(cmd, -max_dq, max_dq);
       }
     }
-    q_next[k] = kp_clip<R>(q[k] + cmd, cfg.lower[k], cfg.upper[k]);  // :243
+    q_next[k] = joint_clip<R>(q[k] + cmd, cfg.lower[k], cfg.upper[k]);  // :243
     dq_next[k] = q_next[k] - q[k];                                   // :244
     R dd = dq_next[k] - dq[k];
     dq_change_ss += dd * dd;
@@ -339,10 +339,7 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
     pact_ss += prev_action[k] * prev_action[k];
     R da = act[k] - prev_action[k];
     dact_ss += da * da;
-    // joint_limit_margin(q_next); KP1/kinematics/joint_limits.py:166-174
-    R span = kp_max<R>(cfg.upper[k] - cfg.lower[k], (R)1e-9);
-    R m = kp_clip<R>((R)2 * kp_min<R>((q_next[k] - cfg.lower[k]) / span, (cfg.upper[k] - q_next[k]) / span), Z, (R)1);
-    margin_min = kp_min<R>(margin_min, m);
+    margin_min = kp_min<R>(margin_min, joint_limit_margin<R>(q_next[k], cfg.lower[k], cfg.upper[k]));  // joint_limits.py:166-174
   }
   R ee_next[6];
   fk_pose6<R>(cfg.fk, q_next, ee_next);  // :246
@@ -489,6 +486,45 @@ __global__ void kp1_fk_kernel(const DevFk<R>* fk, const R* q, R* pose, int64_t n
   for (int k = 0; k < NJ; ++k) qq[k] = q[i * NJ + k];
   fk_pose6<R>(*fk, qq, p);
   for (int k = 0; k < 6; ++k) pose[i * 6 + k] = p[k];
+}
+
+template <typename R>
+__global__ void kp1_pose_error_kernel(const R* curr, const R* goal, R* pos_err, R* ori_err, R* norms, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  R c[6], g[6], pe[3], oe[3], pn, on;
+  for (int k = 0; k < 6; ++k) {
+    c[k] = curr[i * 6 + k];
+    g[k] = goal[i * 6 + k];
+  }
+  pose_error_norms<R>(c, g, pe, oe, &pn, &on);
+  for (int k = 0; k < 3; ++k) {
+    if (pos_err) pos_err[i * 3 + k] = pe[k];
+    if (ori_err) ori_err[i * 3 + k] = oe[k];
+  }
+  if (norms) {
+    norms[i * 2 + 0] = pn;
+    norms[i * 2 + 1] = on;
+  }
+}
+
+template <typename R>
+struct JointLimitsDev { R lower[NJ], upper[NJ], dlim[NJ]; };
+
+template <typename R>
+__global__ void kp1_joint_utils_kernel(const JointLimitsDev<R> lim, const R* q, const R* dq, R* clipped, R* margin, R* q_norm, R* dq_norm, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int k = 0; k < NJ; ++k) {
+    const R lo = lim.lower[k], hi = lim.upper[k];
+    if (q) {
+      const R c = joint_clip<R>(q[i * NJ + k], lo, hi);
+      if (clipped) clipped[i * NJ + k] = c;
+      if (margin) margin[i * NJ + k] = joint_limit_margin<R>(c, lo, hi);
+      if (q_norm) q_norm[i * NJ + k] = joint_normalize_q<R>(q[i * NJ + k], lo, hi);
+    }
+    if (dq && dq_norm) dq_norm[i * NJ + k] = joint_normalize_dq<R>(dq[i * NJ + k], lim.dlim[k]);
+  }
 }
 
 // set_state: scatter row-major fp64 host-provided rows into the SoA state, recompute ee = FK(q)
@@ -1293,6 +1329,52 @@ int kp1_fk_pose6(int32_t device, int32_t real_type, const void* q_dev, void* pos
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   (void)hipFree(dfk);
   if (le != hipSuccess) return fail(KP1_ERR_NO_DEVICE, hipGetErrorString(le));
+  return KP1_OK;
+}
+
+int kp1_pose_error(int32_t device, int32_t real_type, const void* curr_dev, const void* goal_dev, void* pos_err_dev, void* ori_err_dev,
+                   void* norms_dev, int64_t n, void* stream) {
+  if (!curr_dev || !goal_dev || n < 0) return fail(KP1_ERR_INVALID, "bad argument to kp1_pose_error");
+  if (n == 0) return KP1_OK;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(KP1_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+  HIP_TRY(hipSetDevice(device));
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (real_type == KP1_REAL_F64) {
+    hipLaunchKernelGGL(kp1_pose_error_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, (const double*)curr_dev, (const double*)goal_dev,
+                       (double*)pos_err_dev, (double*)ori_err_dev, (double*)norms_dev, n);
+  } else if (real_type == KP1_REAL_F32) {
+    hipLaunchKernelGGL(kp1_pose_error_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)curr_dev, (const float*)goal_dev,
+                       (float*)pos_err_dev, (float*)ori_err_dev, (float*)norms_dev, n);
+  } else {
+    return fail(KP1_ERR_INVALID, "real_type must be KP1_REAL_F32 or KP1_REAL_F64");
+  }
+  HIP_TRY(hipGetLastError());
+  return KP1_OK;
+}
+
+int kp1_joint_utils(int32_t device, int32_t real_type, const kp1_config* cfg, const void* q_dev, const void* dq_dev, void* clipped_dev,
+                    void* margin_dev, void* q_norm_dev, void* dq_norm_dev, int64_t n, void* stream) {
+  if (!cfg || (!q_dev && !dq_dev) || n < 0) return fail(KP1_ERR_INVALID, "bad argument to kp1_joint_utils");
+  if (n == 0) return KP1_OK;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(KP1_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+  HIP_TRY(hipSetDevice(device));
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (real_type == KP1_REAL_F64) {
+    JointLimitsDev<double> lim;
+    for (int k = 0; k < NJ; ++k) { lim.lower[k] = cfg->joints.lower[k]; lim.upper[k] = cfg->joints.upper[k]; lim.dlim[k] = cfg->joints.delta_limit[k]; }
+    hipLaunchKernelGGL(kp1_joint_utils_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, lim, (const double*)q_dev, (const double*)dq_dev,
+                       (double*)clipped_dev, (double*)margin_dev, (double*)q_norm_dev, (double*)dq_norm_dev, n);
+  } else if (real_type == KP1_REAL_F32) {
+    JointLimitsDev<float> lim;
+    for (int k = 0; k < NJ; ++k) { lim.lower[k] = (float)cfg->joints.lower[k]; lim.upper[k] = (float)cfg->joints.upper[k]; lim.dlim[k] = (float)cfg->joints.delta_limit[k]; }
+    hipLaunchKernelGGL(kp1_joint_utils_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, lim, (const float*)q_dev, (const float*)dq_dev,
+                       (float*)clipped_dev, (float*)margin_dev, (float*)q_norm_dev, (float*)dq_norm_dev, n);
+  } else {
+    return fail(KP1_ERR_INVALID, "real_type must be KP1_REAL_F32 or KP1_REAL_F64");
+  }
+  HIP_TRY(hipGetLastError());
   return KP1_OK;
 }
 

@@ -81,6 +81,8 @@ def load() -> C.CDLL:
     L.kp1_rng_get.argtypes = [vp, vp]
     L.kp1_rng_set.argtypes = [vp, vp]
     L.kp1_fk_pose6.argtypes = [i32, i32, vp, vp, i64, vp]
+    L.kp1_pose_error.argtypes = [i32, i32, vp, vp, vp, vp, vp, i64, vp]
+    L.kp1_joint_utils.argtypes = [i32, i32, C.POINTER(kcfg.Kp1Config), vp, vp, vp, vp, vp, vp, i64, vp]
     L.kp1_rng_seed_state.argtypes = [u64, C.POINTER(kcfg.RngState)]
     f32 = C.c_float
     L.kp1_gae_scan.argtypes = [i32, vp, vp, vp, vp, f32, f32, vp, vp, i32, i32, vp]

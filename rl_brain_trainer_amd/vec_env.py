@@ -286,3 +286,41 @@ def fk_pose6(q: torch.Tensor) -> torch.Tensor:
     stream = torch.cuda.current_stream(q.device).cuda_stream
     native.check(L.kp1_fk_pose6(q.device.index or 0, rt, C.c_void_p(q.data_ptr()), C.c_void_p(out.data_ptr()), q.shape[0], C.c_void_p(stream)))
     return out
+
+
+def _real_type(t: torch.Tensor) -> int:
+    if t.dtype not in (torch.float32, torch.float64):
+        raise ValueError("expected a float32 or float64 tensor")
+    if not t.is_cuda:
+        raise native.Kp1Error("needs a device tensor; there is no CPU fallback")
+    return native.REAL_F64 if t.dtype == torch.float64 else native.REAL_F32
+
+
+def pose_error_components(curr_pose6: torch.Tensor, goal_pose6: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """kinematics/pose_utils.py:21-30 batched on the GPU through the device function of the step kernel:
+    (pos_err[n,3], ori_err[n,3] wrapped per component to [-pi, pi), norms[n,2])."""
+    if curr_pose6.shape != goal_pose6.shape or curr_pose6.ndim != 2 or curr_pose6.shape[1] != 6 or curr_pose6.dtype != goal_pose6.dtype:
+        raise ValueError("Expected two pose6 tensors of shape (n, 6) and equal dtype")
+    rt = _real_type(curr_pose6)
+    c, g = curr_pose6.contiguous(), goal_pose6.contiguous()
+    n = c.shape[0]
+    pe, oe, nr = (torch.empty((n, k), dtype=c.dtype, device=c.device) for k in (3, 3, 2))
+    stream = torch.cuda.current_stream(c.device).cuda_stream
+    native.check(native.load().kp1_pose_error(c.device.index or 0, rt, C.c_void_p(c.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(pe.data_ptr()),
+                                              C.c_void_p(oe.data_ptr()), C.c_void_p(nr.data_ptr()), n, C.c_void_p(stream)))
+    return pe, oe, nr
+
+
+def joint_utils(config: kcfg.EnvConfig, q: torch.Tensor, dq: torch.Tensor) -> dict[str, torch.Tensor]:
+    """kinematics/joint_limits.py:133-174 batched on the GPU through the device functions of the hot path:
+    clipped = clip(q), margin = joint_limit_margin(clipped), q_norm = normalize_joint_positions(q), dq_norm = normalize_joint_deltas(dq)."""
+    if q.shape != dq.shape or q.ndim != 2 or q.shape[1] != kcfg.NJ or q.dtype != dq.dtype:
+        raise ValueError("Expected q and dq of shape (n, 7) and equal dtype")
+    rt = _real_type(q)
+    q, dq = q.contiguous(), dq.contiguous()
+    out = {k: torch.empty_like(q) for k in ("clipped", "margin", "q_norm", "dq_norm")}
+    stream = torch.cuda.current_stream(q.device).cuda_stream
+    native.check(native.load().kp1_joint_utils(q.device.index or 0, rt, C.byref(config.c), C.c_void_p(q.data_ptr()), C.c_void_p(dq.data_ptr()),
+                                               *(C.c_void_p(out[k].data_ptr()) for k in ("clipped", "margin", "q_norm", "dq_norm")), q.shape[0],
+                                               C.c_void_p(stream)))
+    return out

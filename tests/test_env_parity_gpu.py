@@ -243,6 +243,55 @@ def test_batched_parity_vs_oracle_f32():
     env.close()
 
 
+def test_config4_randomstart_shard_8192_f32():
+    """BASELINE configs[3]: one 8192-env shard of the 65536-env random-start eval (rank 3 of 8: first_env_id = 3 * 8192,
+    workspace_full_coverage_randomstart_overnight, 160-step episodes, random-start pair sampler).  Production f32 handle vs the fp64
+    oracle on identical actions through one full episode plus the auto-reset: pose error <= 1e-5, reset stage / source indices and step
+    counters bit-exact, PCG64 words of every env bit-exact afterwards; then the size-independence property (env i depends on
+    seed + global id only) against a 64-env handle at the same offset."""
+    cfg = load_golden_config("workspace_full_coverage_randomstart_overnight")
+    n, seed, stage, first = 8192, 931, 10, 3 * 8192
+    assert int(cfg.c.termination.max_episode_steps) == 160
+    env = ArmKinematicVecEnv(cfg, n, seed=seed, real="f32", first_env_id=first)
+    env.set_curriculum_stage(stage)
+    small = ArmKinematicVecEnv(cfg, 64, seed=seed, real="f32", first_env_id=first)
+    small.set_curriculum_stage(stage)
+    ora = orc.OracleVecEnv(cfg, n, seed0=seed, first_env_id=first, stage=stage)
+    o_dev = env.reset().clone()
+    o_small = small.reset().clone()
+    o_ora = ora.reset()
+    assert torch.equal(o_dev[:64], o_small)
+    assert np.max(np.abs(o_dev.cpu().numpy() - o_ora)) <= 2e-6
+    assert np.array_equal(env.info()["stage_index"].cpu().numpy(), ora.field("last_reset_stage"))
+    assert len(np.unique(ora.field("last_reset_stage"))) > 3          # the pair sampler really mixes target stages
+    arng = np.random.default_rng(4)
+    dl = np.array(cfg.c.joints.delta_limit[:]) * cfg.c.env.action_delta_scale
+    worst_pos = worst_ori = worst_perr = 0.0
+    for t in range(160 + 6):
+        a = arng.uniform(-1.0, 1.0, size=(n, 7)).astype(np.float32)
+        goal_q, q = ora.field("goal_q"), ora.field("q")
+        a[: n // 2] = np.clip(0.6 * (goal_q - q) / dl, -1, 1)[: n // 2].astype(np.float32)
+        at = torch.tensor(a, device="cuda")
+        obs, rew, done = env.step(at)
+        o2, r2, d2 = small.step(at[:64].contiguous())
+        assert torch.equal(obs[:64], o2) and torch.equal(rew[:64], r2) and torch.equal(done[:64], d2), t
+        ora.step(a.astype(np.float64))
+        info = env.info()
+        d = np.abs(info["ee_pose6"].double().cpu().numpy().T - ora.field("ee_pose6"))
+        d[:, 3:] = np.abs((d[:, 3:] + np.pi) % (2 * np.pi) - np.pi)
+        worst_pos, worst_ori = max(worst_pos, d[:, :3].max()), max(worst_ori, d[:, 3:].max())
+        live = ora.field("episode_step") > 0     # envs that did not just auto-reset: their info norms are those of this step
+        perr_o = np.linalg.norm(ora.field("goal_pose6")[:, :3] - ora.field("ee_pose6")[:, :3], axis=1)   # pose_utils.py:11-30
+        worst_perr = max(worst_perr, float(np.max(np.abs(info["position_error_norm"].double().cpu().numpy() - perr_o)[live])))
+        assert np.array_equal(info["stage_index"].cpu().numpy(), ora.field("last_reset_stage")), t
+        assert np.array_equal(info["step_count"].cpu().numpy(), ora.field("episode_step")), t
+    assert int(ora.field("episode_step").max()) < 160                      # every env went through at least one auto-reset
+    assert worst_pos <= F32_POSE_TOL and worst_ori <= F32_POSE_TOL and worst_perr <= F32_POSE_TOL, (worst_pos, worst_ori, worst_perr)
+    assert np.array_equal(env.rng_state(), np.array([orc.rng_words(ora.envs[i].rng) for i in range(n)]))
+    env.close()
+    small.close()
+
+
 def test_full_size_properties_config3():
     """BASELINE config 3 (stage 11, 32768 envs): size-independent properties."""
     cfg = load_golden_config("workspace_expansion_1h_extend")
@@ -328,3 +377,48 @@ def test_random_reward_config_parity_vs_oracle_f64(mode, case_ids):
             worst_c = max(worst_c, float(np.max(np.abs(comps.cpu().numpy().T - oc))))
         assert worst_r <= 1e-9 and worst_c <= 1e-9, (cid, worst_r, worst_c)
         env.close()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_pose_error_golden_gpu(dtype):
+    """pose_error.npz (512 reference cases incl. the +-pi / +-3pi wrap edges) through wrap_to_pi<R> / pose_error_norms<R> on the device."""
+    from rl_brain_trainer_amd.vec_env import pose_error_components
+
+    g = np.load(GOLDEN / "pose_error.npz")
+    curr, goal = (torch.tensor(g[k], dtype=dtype, device="cuda") for k in ("curr", "goal"))
+    pe, oe, norms = (t.double().cpu().numpy() for t in pose_error_components(curr, goal))
+    if dtype == torch.float64:
+        assert np.array_equal(pe, g["pos_err"])
+        assert np.max(np.abs(oe - g["ori_err"])) <= 1e-15
+        assert np.all(oe >= -np.pi) and np.all(oe < np.pi)
+    else:
+        # the f32 handle sees f32-rounded poses: compare against the reference formula on those inputs; a raw difference within one f32
+        # ulp of +-pi may land on the other end of [-pi, pi) -- compare modulo 2 pi
+        c32, g32 = g["curr"].astype(np.float32).astype(np.float64), g["goal"].astype(np.float32).astype(np.float64)
+        assert np.max(np.abs(pe - (g32[:, :3] - c32[:, :3]))) <= 1e-6
+        d = oe - ((g32[:, 3:] - c32[:, 3:] + np.pi) % (2 * np.pi) - np.pi)
+        assert np.max(np.abs((d + np.pi) % (2 * np.pi) - np.pi)) <= 1e-5
+        assert np.all(oe >= -np.pi - 1e-6) and np.all(oe <= np.pi + 1e-6)
+    tol = 1e-14 if dtype == torch.float64 else 1e-5
+    assert np.max(np.abs(norms[:, 0] - np.linalg.norm(pe, axis=1))) <= tol and np.max(np.abs(norms[:, 1] - np.linalg.norm(oe, axis=1))) <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_joint_utils_golden_gpu(dtype):
+    """joint_utils.npz through the device joint helpers the step kernel and the observation builder use."""
+    from rl_brain_trainer_amd.vec_env import joint_utils
+
+    g = np.load(GOLDEN / "joint_utils.npz")
+    cfg = load_golden_config("approach_default")
+    assert np.array_equal(np.array(cfg.c.joints.lower[:]), g["lower"]) and np.array_equal(np.array(cfg.c.joints.delta_limit[:]), g["delta_limits"])
+    out = joint_utils(cfg, torch.tensor(g["q"], dtype=dtype, device="cuda"), torch.tensor(g["dq"], dtype=dtype, device="cuda"))
+    out = {k: v.double().cpu().numpy() for k, v in out.items()}
+    if dtype == torch.float64:
+        assert np.array_equal(out["clipped"], g["clipped"])
+        for k in ("margin", "q_norm", "dq_norm"):
+            assert np.max(np.abs(out[k] - g[k])) <= 1e-15, k
+    else:
+        for k in ("clipped", "margin", "q_norm", "dq_norm"):
+            assert np.max(np.abs(out[k] - g[k])) <= 2e-6, k
+    for k, (lo, hi) in (("margin", (0.0, 1.0)), ("q_norm", (-1.0, 1.0)), ("dq_norm", (-1.0, 1.0))):
+        assert out[k].min() >= lo and out[k].max() <= hi

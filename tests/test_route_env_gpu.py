@@ -40,6 +40,7 @@ def test_route_dataset_on_device(route_q):
 
 
 @pytest.mark.parametrize("name,cfg_name,max_index", [("seq_prefix120", "route_curriculum_prefix120_routeobs_sequence2", 120),
+                                                     ("seq_prefix170", "route_curriculum_prefix170_routeobs_sequence2", 170),   # BASELINE configs[4]
                                                      ("seq_prefix20", "route_curriculum_prefix20_sequence2", 20),
                                                      ("single_default", "route_curriculum_default", 20)])
 def test_route_env_replays_reference_trace_f64(route_q, name, cfg_name, max_index):
@@ -91,12 +92,14 @@ def test_route_env_replays_reference_trace_f64(route_q, name, cfg_name, max_inde
     env.close()
 
 
-def test_route_env_f32_batch_matches_oracle_and_explicit_resets(route_q):
+@pytest.mark.parametrize("prefix", [120, 170])
+def test_route_env_f32_batch_matches_oracle_and_explicit_resets(route_q, prefix):
     """256 fp32 device envs vs 256 serial oracle envs under a noisy servo policy: same reset draws (bit exact stream), rewards within
-    fp32 tolerance, identical waypoint hand-overs; then explicit route_index resets."""
-    cfgd = _cfg_dict("route_curriculum_prefix120_routeobs_sequence2")
+    fp32 tolerance, identical waypoint hand-overs; then explicit route_index resets.  prefix 170 = BASELINE configs[4]."""
+    cfgd = _cfg_dict(f"route_curriculum_prefix{prefix}_routeobs_sequence2")
     base = kcfg.to_env_config(cfgd)
-    rc = rcfg.route_config_from_dict(cfgd, max_route_index=120)
+    rc = rcfg.route_config_from_dict(cfgd, max_route_index=prefix)
+    assert int(rc.reset.max_route_index) == prefix
     N = 256
     env = RouteVecEnv(base, rc, route_q, N, seed=817)
     route = ro.Route(route_q)
@@ -105,6 +108,8 @@ def test_route_env_f32_batch_matches_oracle_and_explicit_resets(route_q):
     for i, o in enumerate(oracles):
         ob = o.reset(seed=817 + i)
         assert np.max(np.abs(ob - obs[i])) <= 2e-6
+    start_idx = env.info()["route_index"].cpu().numpy()
+    assert int(start_idx.max()) <= prefix and (prefix == 120 or int(start_idx.max()) > 120)   # the window really reaches past 120
     dl = np.array(base.c.joints.delta_limit[:]) * base.c.env.action_delta_scale
     rng = np.random.default_rng(0)
     handovers = mismatched = 0

@@ -73,7 +73,7 @@ def test_route_reward_cases(route):
     assert worst <= 1e-12, worst
 
 
-@pytest.mark.parametrize("tag", ["prefix120", "prefix20", "replay", "forced_segment"])
+@pytest.mark.parametrize("tag", ["prefix120", "prefix20", "replay", "forced_segment", "prefix170"])
 def test_route_reset_sampler_streams(route, tag):
     g = np.load(GOLDEN / f"route_resets_{tag}.npz")
     cfg = rcfg.route_config_from_dict({"route": {"reset": json.loads(str(g["reset_config"]))}})
@@ -93,6 +93,7 @@ def test_route_reset_sampler_streams(route, tag):
 
 
 @pytest.mark.parametrize("name,cfg_name,max_index", [("seq_prefix120", "route_curriculum_prefix120_routeobs_sequence2", 120),
+                                                     ("seq_prefix170", "route_curriculum_prefix170_routeobs_sequence2", 170),   # BASELINE configs[4]
                                                      ("seq_prefix20", "route_curriculum_prefix20_sequence2", 20),
                                                      ("single_default", "route_curriculum_default", 20)])
 def test_route_env_traces(route, name, cfg_name, max_index):
