@@ -39,9 +39,12 @@ extern "C" {
 typedef enum kp1_status {
   KP1_OK = 0,
   KP1_ERR_INVALID = -1,   /* bad argument / shape (the reference raises ValueError) */
-  KP1_ERR_NO_DEVICE = -2, /* no HIP device or HIP runtime failure */
-  KP1_ERR_ALLOC = -3,
-  KP1_ERR_UNSUPPORTED = -4 /* mode outside {approach, dock} */
+  KP1_ERR_NO_DEVICE = -2, /* no HIP device (hipErrorNoDevice / hipErrorInvalidDevice): this library has no CPU path */
+  KP1_ERR_ALLOC = -3,     /* device or host memory exhausted (hipErrorOutOfMemory) */
+  KP1_ERR_UNSUPPORTED = -4, /* mode outside {approach, dock} */
+  KP1_ERR_LAUNCH = -5,    /* a kernel launch was rejected (bad configuration, LDS / register budget) */
+  KP1_ERR_RUNTIME = -6    /* any other HIP runtime failure, incl. an asynchronous fault of an earlier kernel surfacing at this call;
+                             kp1_last_error() names the HIP call and hipGetErrorString */
 } kp1_status;
 
 /* policy modes; arm_kinematic_env.py:544-551 (_mode_index). bridge/dock_coarse are out of scope. */

@@ -893,7 +893,7 @@ int launch_step(kp1_env* e, const void* actions, float* obs, void* reward, uint8
     if (comps) hipLaunchKernelGGL((kp1_step_kernel<R, KP1_MODE_APPROACH, true>), grid, dim3(block), 0, e->stream, a);
     else hipLaunchKernelGGL((kp1_step_kernel<R, KP1_MODE_APPROACH, false>), grid, dim3(block), 0, e->stream, a);
   }
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }
 
@@ -907,7 +907,7 @@ int launch_reset(kp1_env* e, const uint8_t* mask, const ResetOptsDev& opts, int 
   else
     hipLaunchKernelGGL((kp1_reset_kernel<R, KP1_MODE_APPROACH>), grid, dim3(block), 0, e->stream, state_of<R>(e),
                        (const DevCfg<R>*)e->dev_cfg, e->dev_smp, e->dev_handoff, mask, opts, e->stage, obs, e->obs_stride);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }
 
@@ -1119,7 +1119,7 @@ int kp1_observe(kp1_env* e, float* obs_dev) {
     hipLaunchKernelGGL(kp1_observe_kernel<double>, grid, dim3(block), 0, e->stream, state_of<double>(e), (const DevCfg<double>*)e->dev_cfg, e->mode, obs_dev, e->obs_stride);
   else
     hipLaunchKernelGGL(kp1_observe_kernel<float>, grid, dim3(block), 0, e->stream, state_of<float>(e), (const DevCfg<float>*)e->dev_cfg, e->mode, obs_dev, e->obs_stride);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }
 
@@ -1221,7 +1221,7 @@ int kp1_get_state(kp1_env* e, double* q, double* dq, double* prev_action, double
     hipLaunchKernelGGL(kp1_get_state_kernel<double>, grid, dim3(block), 0, e->stream, state_of<double>(e), dq_q, dq_dq, dq_pa, dq_gq, dq_gp);
   else
     hipLaunchKernelGGL(kp1_get_state_kernel<float>, grid, dim3(block), 0, e->stream, state_of<float>(e), dq_q, dq_dq, dq_pa, dq_gq, dq_gp);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kp1::launch_status());
   if (q) HIP_TRY(hipMemcpyAsync(q, dq_q, sizeof(double) * n * NJ, hipMemcpyDeviceToHost, e->stream));
   if (dq) HIP_TRY(hipMemcpyAsync(dq, dq_dq, sizeof(double) * n * NJ, hipMemcpyDeviceToHost, e->stream));
   if (prev_action) HIP_TRY(hipMemcpyAsync(prev_action, dq_pa, sizeof(double) * n * NJ, hipMemcpyDeviceToHost, e->stream));
@@ -1258,7 +1258,7 @@ int kp1_set_state(kp1_env* e, const double* q, const double* dq, const double* p
   else
     hipLaunchKernelGGL(kp1_set_state_kernel<float>, grid, dim3(block), 0, e->stream, state_of<float>(e), (const DevCfg<float>*)e->dev_cfg,
                        dev[0], dev[1], dev[2], dev[3], dev[4], capture_entry_metrics);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }
 
@@ -1349,7 +1349,7 @@ int kp1_pose_error(int32_t device, int32_t real_type, const void* curr_dev, cons
   } else {
     return fail(KP1_ERR_INVALID, "real_type must be KP1_REAL_F32 or KP1_REAL_F64");
   }
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }
 
@@ -1374,7 +1374,7 @@ int kp1_joint_utils(int32_t device, int32_t real_type, const kp1_config* cfg, co
   } else {
     return fail(KP1_ERR_INVALID, "real_type must be KP1_REAL_F32 or KP1_REAL_F64");
   }
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }
 

@@ -490,8 +490,8 @@ __global__ void __launch_bounds__(256) head_train_kernel(const HeadArgs a) {
   const int hpitch = a.Hp + 4;             // row pitch of the staged activations: conflict-free float4 row reads
   float* w3s = smem;                       // [8][Hp]
   float* dout = smem + HEADS * a.Hp;       // [HEAD_ROWS][8] : d loss / d (mean_0..6, value)
-  float* red = dout + HEAD_ROWS * 8;       // [20] small per-block accumulators
-  float* adv_ms = red + 20;                // [2] (+2 pad)
+  float* red = dout + HEAD_ROWS * 8;       // [4 waves][20] per-wave partial sums
+  float* adv_ms = red + 80;                // [2] (+2 pad)
   float* h2s = adv_ms + 4;                 // [2][HEAD_ROWS][hpitch]: this block's rows of both nets, read from HBM once
   for (int k = threadIdx.x; k < HEADS * a.Hp; k += 256) w3s[k] = a.w3[k];
   {
@@ -512,7 +512,6 @@ __global__ void __launch_bounds__(256) head_train_kernel(const HeadArgs a) {
       *reinterpret_cast<f32x4*>(h2s + (net * HEAD_ROWS + r) * hpitch + 4 * c4) = v[j];
     }
   }
-  if (threadIdx.x < 20) red[threadIdx.x] = 0.f;
   // fixed-order parallel reduction of the per-block advantage partials (wave 0; a.n_adv_partials <= 128)
   double ps = 0.0, pss = 0.0;
   if (a.adv_mode == 1 && threadIdx.x < 64) {
@@ -584,7 +583,7 @@ __global__ void __launch_bounds__(256) head_train_kernel(const HeadArgs a) {
   }
   dout[row_l * 8 + out] = ok ? d : 0.f;
   // per-block sums over rows of: d loss/d log_std_out, d loss/d head bias_out, loss terms.  Lanes with equal (t & 7) hold
-  // the same `out`: reduce inside the wave by shuffles, across the 4 waves through LDS atomics (uncontended, 4 adders).
+  // the same `out`: reduce inside the wave by shuffles, across the 4 waves through per-wave LDS slots summed in a fixed order.
   float gls = (ok && out < ACT) ? g_logp * (z * z - 1.f) : 0.f;
   gls += __shfl_xor(gls, 8);
   gls += __shfl_xor(gls, 16);
@@ -593,22 +592,31 @@ __global__ void __launch_bounds__(256) head_train_kernel(const HeadArgs a) {
   dsum += __shfl_xor(dsum, 8);
   dsum += __shfl_xor(dsum, 16);
   dsum += __shfl_xor(dsum, 32);
-  float* small = red;  // [0..3) loss sums, then 8 bias grads at +4, 7 log_std grads at +12  (20 floats, zeroed below)
-  if ((threadIdx.x & 63) < 8) {
-    atomicAdd(&small[4 + out], dsum);
-    if (out < ACT) atomicAdd(&small[12 + out], gls);
+  // per-wave partials in LDS, combined in a fixed order below (no float atomics: bitwise reproducible run to run).
+  // red layout: [wave 0..3][20] = 3 loss sums, pad, 8 bias grads at +4, 7 log_std grads at +12
+  float pl_w = out == 7 ? pl : 0.f, vl_w = out == 7 ? vl : 0.f, kl_w = out == 7 ? kl : 0.f;
+#pragma unroll
+  for (int off = 8; off < 64; off <<= 1) {
+    pl_w += __shfl_xor(pl_w, off);
+    vl_w += __shfl_xor(vl_w, off);
+    kl_w += __shfl_xor(kl_w, off);
   }
-  if (out == 7) {
-    atomicAdd(&small[0], pl);
-    atomicAdd(&small[1], vl);
-    atomicAdd(&small[2], kl);
+  const int wave_ = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < 8) {
+    red[wave_ * 20 + 4 + out] = dsum;
+    if (out < ACT) red[wave_ * 20 + 12 + out] = gls;
+    if (out == 7) {
+      red[wave_ * 20 + 0] = pl_w;
+      red[wave_ * 20 + 1] = vl_w;
+      red[wave_ * 20 + 2] = kl_w;
+    }
   }
   __syncthreads();
   float* part = a.hpart + (int64_t)blockIdx.x * a.hpart_stride;
-  if (threadIdx.x < 19) {
+  if (threadIdx.x < 18) {
     const int k = threadIdx.x;  // 0..7 bias grads, 8..14 log_std grads, 15..17 loss sums
-    const float v = k < 8 ? small[4 + k] : (k < 15 ? small[12 + (k - 8)] : small[k - 15]);
-    if (k < 18) part[10 * a.Hp + k] = v;
+    const int slot = k < 8 ? 4 + k : (k < 15 ? 12 + (k - 8) : k - 15);
+    part[10 * a.Hp + k] = ((red[slot] + red[20 + slot]) + red[40 + slot]) + red[60 + slot];
   }
   // phase 2: one thread per hidden column; dZ2 = (dOut W3) * (1 - h2^2), head weight grads, layer-2 bias grads
   const int rows_here = min(HEAD_ROWS, a.n - blockIdx.x * HEAD_ROWS);
@@ -1149,7 +1157,7 @@ int launch_forward_layers(kp1_mlp* m, const float* obs, int obs_stride, const in
   g.K = Hp; g.Kreal = Hp;
   rc = launch_nt<EPI_BIAS_TANH>(g, stream);
   if (rc != KP1_OK) return rc;
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }
 
@@ -1258,7 +1266,7 @@ int kp1_mlp_set_option(kp1_mlp* m, int32_t option, int32_t value) {
       Packed k = m->k;
       k.formats = PACK_SLAB | PACK_FRAG;
       hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((m->L.total + 255) / 256)), dim3(256), 0, (hipStream_t)0, m->last_params, m->L, k);
-      HIP_TRY(hipGetLastError());
+      HIP_TRY(kp1::launch_status());
       HIP_TRY(hipDeviceSynchronize());
       m->slab_stale = false;
     }
@@ -1286,7 +1294,7 @@ int kp1_mlp_pack_weights(kp1_mlp* m, const float* params, void* stream) {
   Packed k = m->k;
   k.formats = PACK_SLAB | PACK_FRAG;
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((m->L.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, m->L, k);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kp1::launch_status());
   m->last_params = params;
   m->slab_stale = false;
   return KP1_OK;
@@ -1307,7 +1315,7 @@ int kp1_mlp_forward(kp1_mlp* m, const float* obs, int32_t obs_stride, int32_t n,
     fa.noise = noise; fa.mean = mean; fa.value = value; fa.action = action; fa.clipped = clipped_action; fa.log_prob = log_prob;
     rc = launch_fused_infer(fa, (hipStream_t)stream);
     if (rc != KP1_OK) return rc;
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(kp1::launch_status());
     return KP1_OK;
   }
   rc = launch_forward_layers(m, obs, obs_stride, nullptr, n, (hipStream_t)stream);
@@ -1317,7 +1325,7 @@ int kp1_mlp_forward(kp1_mlp* m, const float* obs, int32_t obs_stride, int32_t n,
   a.w3 = m->k.w3; a.b3 = m->k.b3; a.log_std = m->k.log_std;
   a.noise = noise; a.mean = mean; a.value = value; a.action = action; a.clipped = clipped_action; a.log_prob = log_prob;
   hipLaunchKernelGGL(head_infer_kernel, dim3((n + HEAD_ROWS - 1) / HEAD_ROWS), dim3(256), sizeof(float) * HEADS * m->Hp, (hipStream_t)stream, a);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }
 
@@ -1369,7 +1377,7 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
     a.hpart = m->hpart; a.hpart_stride = hpart_stride;
     {
       const dim3 hgrid((n + HEAD_ROWS - 1) / HEAD_ROWS);
-      const size_t hbytes = sizeof(float) * (HEADS * Hp + HEAD_ROWS * 8 + 24 + 2 * HEAD_ROWS * (Hp + 4));
+      const size_t hbytes = sizeof(float) * (HEADS * Hp + HEAD_ROWS * 8 + 84 + 2 * HEAD_ROWS * (Hp + 4));
       if (Hp == 256) {
         HIP_TRY(hipFuncSetAttribute((const void*)head_train_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hbytes));
         hipLaunchKernelGGL(head_train_kernel<256>, hgrid, dim3(256), hbytes, stream, a);
@@ -1440,7 +1448,7 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   m->n_finalize_blocks = n_main + (int)((finalize_wide_count(L) + 3 + 31) / 32);
   if (m->n_finalize_blocks > 2048) return fail(KP1_ERR_INVALID, "parameter vector too large for the sum-of-squares partial buffer");
   hipLaunchKernelGGL(grad_finalize_kernel, dim3(m->n_finalize_blocks), dim3(256), 0, stream, f, n_main);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }
 
@@ -1578,7 +1586,7 @@ int kp1_mlp_adam_step(kp1_mlp* m, float* params, float* grad, float* exp_avg, fl
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, params, grad, exp_avg, exp_avg_sq, n,
                      norm_partials, n_norm_partials, lr, eps, max_grad_norm, bc1, std::sqrt(bc2), m->L, kfmt, zero_grad,
                      step > 0 ? (const int*)nullptr : (const int*)m->step_dev, host_step, (const int*)m->step_dev + 1);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }
 

@@ -154,7 +154,7 @@ int kp1_gae_scan(int32_t device, const float* rewards, const float* values, cons
   const int block = N <= 16384 ? 64 : 256;
   hipLaunchKernelGGL(gae_scan_kernel, dim3((N + block - 1) / block), dim3(block), 0, (hipStream_t)stream, rewards, values, dones, last_values,
                      gamma, gae_lambda, advantages, returns, T, N);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }
 
@@ -200,7 +200,7 @@ int kp1_adv_minibatch_sums(int32_t device, const float* advantages, const int64_
   if (rc != KP1_OK) return rc;
   const int64_t n_mb = (total + minibatch - 1) / minibatch;
   hipLaunchKernelGGL(adv_minibatch_sums_kernel, dim3((unsigned)n_mb), dim3(256), 0, (hipStream_t)stream, advantages, idx, total, minibatch, out_sums);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }
 
@@ -211,7 +211,7 @@ int kp1_bootstrap_truncated(int32_t device, float* rewards, const float* termina
   if (rc != KP1_OK) return rc;
   hipLaunchKernelGGL(bootstrap_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rewards, terminal_values, dones,
                      gamma, count);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }
 
@@ -246,7 +246,7 @@ int kp1_curriculum_observe(int32_t device, kp1_curriculum_state* st_dev, const u
   int rc = check_device(device);
   if (rc != KP1_OK) return rc;
   hipLaunchKernelGGL(curriculum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, st_dev, dones, n, steps_per_call);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }
 int kp1_curriculum_read(int32_t device, const kp1_curriculum_state* st_dev, kp1_curriculum_state* out_host, void* stream) {
