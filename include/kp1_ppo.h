@@ -70,6 +70,12 @@ int kp1_curriculum_destroy(int32_t device, kp1_curriculum_state* st_dev);
 /* _on_step (callbacks.py:71-92): consume dones[0..n) (KP1_DONE_* bits) in index order; steps_per_call = env steps this
  * call represents (n_envs * world_size) for the num_timesteps clock. */
 int kp1_curriculum_observe(int32_t device, kp1_curriculum_state* st_dev, const uint8_t* dones, int32_t n, int32_t steps_per_call, void* stream);
+/* Data-parallel form: dones = the all-gathered [world][chunk_steps][n_local] done bytes of a chunk of env steps (rank-major).  Replayed
+ * step by step and, inside a step, rank by rank = global env id order, i.e. exactly the (done, info) sequence the reference callback
+ * would see on one VecEnv of world * n_local envs; the clock advances by world * n_local per env step.  A promotion takes effect for
+ * the resets of the NEXT chunk (every rank runs this on identical bytes, so all ranks switch together). */
+int kp1_curriculum_observe_chunk(int32_t device, kp1_curriculum_state* st_dev, const uint8_t* dones, int32_t n_local, int32_t chunk_steps,
+                                 int32_t world, void* stream);
 int kp1_curriculum_read(int32_t device, const kp1_curriculum_state* st_dev, kp1_curriculum_state* out_host, void* stream);
 /* make kp1_step take its curriculum stage from *stage_dev (e.g. &tracker->stage_index) instead of kp1_set_stage */
 int kp1_bind_stage_ptr(kp1_env* env, const int32_t* stage_dev);
@@ -131,7 +137,18 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
 /* KP1_MLP_OPT_STEP_COUNT: set the device-resident optimiser step count (PPO.load restores torch.optim.Adam's state, whose per-tensor
  * `step` feeds the bias corrections); kp1_mlp_loss_grad increments it, kp1_mlp_adam_step(step = 0) reads it. */
 #define KP1_MLP_OPT_STEP_COUNT 3
+/* KP1_MLP_OPT_PROFILE (default 0): record a HIP-event pair around every kernel launch of the optimiser step, on the launch stream and in
+ * the real launch sequence, so that a kernel's average duration is measured in situ (caches in the state the previous kernel of the
+ * step left them) rather than in a back-to-back micro loop.  kp1_mlp_profile_read waits for the recorded launches and returns, per
+ * slot, the average duration in microseconds and the launch count since the last read.  Not usable while a hipGraph is being captured. */
+#define KP1_MLP_OPT_PROFILE 4
+#define KP1_MLP_PROFILE_SLOTS 4
+#define KP1_MLP_PROFILE_TILE 0      /* mlp_tile_kernel<true, .>: forward + loss + activation backward of both nets */
+#define KP1_MLP_PROFILE_WGRAD 1     /* gemm_tn_frag_kernel: dW2 + dW1 of both nets */
+#define KP1_MLP_PROFILE_FINALIZE 2  /* grad_finalize_kernel */
+#define KP1_MLP_PROFILE_ADAM 3      /* (sum of squares +) adam_kernel */
 int kp1_mlp_set_option(kp1_mlp* m, int32_t option, int32_t value);
+int kp1_mlp_profile_read(kp1_mlp* m, float* out_us /* [KP1_MLP_PROFILE_SLOTS] */, int32_t* out_launches /* [KP1_MLP_PROFILE_SLOTS] */);
 
 /* clip_grad_norm_(max_norm) + Adam(beta 0.9/0.999, eps) step on the flat vectors; the same pass repacks the kernel-format
  * weights.  step = 1-based Adam step count, or <= 0 to use the device-resident counter that every kp1_mlp_loss_grad call

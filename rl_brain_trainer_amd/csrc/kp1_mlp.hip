@@ -1021,7 +1021,36 @@ struct kp1_mlp {
   const float* last_params = nullptr;
   bool slab_stale = false;
   std::vector<void*> allocs;
+  // KP1_MLP_OPT_PROFILE: HIP-event pairs around every launch of the optimiser step, on the launch stream, in the real launch sequence
+  // (tile -> weight gradients -> finalize -> Adam), read back by kp1_mlp_profile_read.  Off in production (events cannot be recorded
+  // into a captured graph replay usefully, and they add a few us of host work per launch).
+  int profile = 0;
+  struct ProfPair { hipEvent_t a, b; };
+  std::vector<ProfPair> prof[KP1_MLP_PROFILE_SLOTS];
+  int prof_used[KP1_MLP_PROFILE_SLOTS] = {0, 0, 0, 0};
 };
+
+namespace {
+// records the a-event now and the b-event when it goes out of scope
+struct ProfScope {
+  kp1_mlp* m; int slot; hipStream_t stream; bool on;
+  ProfScope(kp1_mlp* m_, int slot_, hipStream_t s_) : m(m_), slot(slot_), stream(s_), on(m_->profile != 0) {
+    if (!on) return;
+    auto& v = m->prof[slot];
+    if (m->prof_used[slot] >= (int)v.size()) {
+      kp1_mlp::ProfPair p{};
+      if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) { on = false; return; }
+      v.push_back(p);
+    }
+    (void)hipEventRecord(v[m->prof_used[slot]].a, stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(m->prof[slot][m->prof_used[slot]].b, stream);
+    m->prof_used[slot] += 1;
+  }
+};
+}  // namespace
 
 namespace {
 
@@ -1252,6 +1281,11 @@ int kp1_mlp_destroy(kp1_mlp* m) {
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
   for (void* p : m->allocs) (void)hipFree(p);
+  for (auto& v : m->prof)
+    for (auto& pr : v) {
+      (void)hipEventDestroy(pr.a);
+      (void)hipEventDestroy(pr.b);
+    }
   delete m;
   return KP1_OK;
 }
@@ -1270,6 +1304,11 @@ int kp1_mlp_set_option(kp1_mlp* m, int32_t option, int32_t value) {
       HIP_TRY(hipDeviceSynchronize());
       m->slab_stale = false;
     }
+    return KP1_OK;
+  }
+  if (option == KP1_MLP_OPT_PROFILE) {
+    m->profile = value ? 1 : 0;
+    for (int k = 0; k < KP1_MLP_PROFILE_SLOTS; ++k) m->prof_used[k] = 0;
     return KP1_OK;
   }
   if (option == KP1_MLP_OPT_STEP_COUNT) {   // optimiser steps taken so far (resuming from a checkpoint's Adam state)
@@ -1361,7 +1400,10 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
     fa.clip_range = clip_range; fa.vf_coef = vf_coef; fa.inv_count = inv_count;
     fa.h1 = m->h1; fa.dz2 = m->dz2; fa.dz1 = m->dz1; fa.act_stride = act_stride; fa.xf = m->xf;
     fa.bslab = m->bslab; fa.hpart = m->hpart; fa.hpart_stride = hpart_stride;
-    rc = launch_fused(fa, stream);
+    {
+      ProfScope ps(m, KP1_MLP_PROFILE_TILE, stream);
+      rc = launch_fused(fa, stream);
+    }
     if (rc != KP1_OK) return rc;
   } else {
     rc = launch_forward_layers(m, obs, obs_stride, idx, n, stream);
@@ -1413,7 +1455,10 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
     t.cg1 = up8((t.groups + KP1_TN_SPLIT1 - 1) / KP1_TN_SPLIT1);   // ~64 chunks x 4 tiles of quarter-size dW1 workgroups
     t.n_chunks2 = (t.groups + t.cg2 - 1) / t.cg2;
     t.n_chunks1 = (t.groups + t.cg1 - 1) / t.cg1;
-    rc = launch_tn_frag(t, stream);
+    {
+      ProfScope ps(m, KP1_MLP_PROFILE_WGRAD, stream);
+      rc = launch_tn_frag(t, stream);
+    }
     if (rc != KP1_OK) return rc;
     s2_n = t.n_chunks2;
     s1_n = t.n_chunks1;
@@ -1447,8 +1492,30 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   const int n_main = (int)((L.total + 255) / 256);
   m->n_finalize_blocks = n_main + (int)((finalize_wide_count(L) + 3 + 31) / 32);
   if (m->n_finalize_blocks > 2048) return fail(KP1_ERR_INVALID, "parameter vector too large for the sum-of-squares partial buffer");
-  hipLaunchKernelGGL(grad_finalize_kernel, dim3(m->n_finalize_blocks), dim3(256), 0, stream, f, n_main);
+  {
+    ProfScope ps(m, KP1_MLP_PROFILE_FINALIZE, stream);
+    hipLaunchKernelGGL(grad_finalize_kernel, dim3(m->n_finalize_blocks), dim3(256), 0, stream, f, n_main);
+  }
   HIP_TRY(kp1::launch_status());
+  return KP1_OK;
+}
+
+int kp1_mlp_profile_read(kp1_mlp* m, float* out_us, int32_t* out_launches) {
+  if (!m || !out_us || !out_launches) return fail(KP1_ERR_INVALID, "NULL argument to kp1_mlp_profile_read");
+  int rc = mlp_check_device(m);
+  if (rc != KP1_OK) return rc;
+  for (int k = 0; k < KP1_MLP_PROFILE_SLOTS; ++k) {
+    double total_ms = 0.0;
+    for (int i = 0; i < m->prof_used[k]; ++i) {
+      HIP_TRY(hipEventSynchronize(m->prof[k][i].b));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, m->prof[k][i].a, m->prof[k][i].b));
+      total_ms += ms;
+    }
+    out_launches[k] = m->prof_used[k];
+    out_us[k] = m->prof_used[k] > 0 ? (float)(total_ms * 1e3 / m->prof_used[k]) : 0.f;
+    m->prof_used[k] = 0;
+  }
   return KP1_OK;
 }
 
@@ -1572,6 +1639,7 @@ int kp1_mlp_adam_step(kp1_mlp* m, float* params, float* grad, float* exp_avg, fl
   const bool fused_norm = (zero_grad & 2) && m->n_finalize_blocks > 0;
   const double* norm_partials = fused_norm ? m->partials + 2 * N_PARTIALS : m->partials + N_PARTIALS;
   const int n_norm_partials = fused_norm ? m->n_finalize_blocks : N_PARTIALS;
+  ProfScope ps(m, KP1_MLP_PROFILE_ADAM, stream);
   if (!fused_norm) hipLaunchKernelGGL(sumsq_partials_kernel, dim3(N_PARTIALS), dim3(256), 0, stream, grad, n, m->partials + N_PARTIALS);
   zero_grad = 0;  // gradients are overwritten by the next finalize; nothing to clear
   // step <= 0: use the device-resident counter that kp1_mlp_loss_grad's finalize kernel increments (graph-replay safe)

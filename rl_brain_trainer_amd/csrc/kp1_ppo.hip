@@ -45,8 +45,7 @@ __global__ void __launch_bounds__(256) bootstrap_kernel(float* __restrict__ rewa
 // and condenses them into a 64-bit done mask and a success mask, so 4096 envs cost one round of loads; a ballot skips
 // the common case where no episode ended (95 of 96 steps at Stage 5).  Finished episodes are then replayed strictly in
 // env order by lane 0 (the masks of lane k are fetched with a shuffle), which is what the reference's sequential scan does.
-__global__ void __launch_bounds__(64) curriculum_kernel(kp1_curriculum_state* __restrict__ st, const uint8_t* __restrict__ dones, int n,
-                                                        int steps_per_call) {
+__device__ __forceinline__ void curriculum_scan(kp1_curriculum_state* __restrict__ st, const uint8_t* __restrict__ dones, int n, int steps_per_call) {
   const int lane = threadIdx.x;
   if (lane == 0) st->num_timesteps += steps_per_call;
   for (int base = 0; base < n; base += 64 * 64) {
@@ -132,6 +131,22 @@ __global__ void __launch_bounds__(64) curriculum_kernel(kp1_curriculum_state* __
       st->ring_head = head;
     }
   }
+}
+
+__global__ void __launch_bounds__(64) curriculum_kernel(kp1_curriculum_state* __restrict__ st, const uint8_t* __restrict__ dones, int n,
+                                                        int steps_per_call) {
+  curriculum_scan(st, dones, n, steps_per_call);
+}
+
+// Data-parallel rollouts exchange the done bytes once per CHUNK of env steps instead of once per step: `dones` is the all-gathered
+// [world][chunk_steps][n_local] block (rank-major, as all_gather_into_tensor lays it out).  The tracker replays it in the order the
+// reference callback would have seen a single VecEnv of world * n_local envs: step by step, and inside a step rank by rank = global
+// env id order (callbacks.py:78-91).  One wave; the state written by lane 0 at the end of a scan is read back by lane 0 in the next.
+__global__ void __launch_bounds__(64) curriculum_chunk_kernel(kp1_curriculum_state* __restrict__ st, const uint8_t* __restrict__ dones, int n_local,
+                                                              int chunk_steps, int world, int steps_per_env_step) {
+  for (int t = 0; t < chunk_steps; ++t)
+    for (int r = 0; r < world; ++r)
+      curriculum_scan(st, dones + ((int64_t)r * chunk_steps + t) * n_local, n_local, r == 0 ? steps_per_env_step : 0);
 }
 
 int check_device(int device) {
@@ -246,6 +261,15 @@ int kp1_curriculum_observe(int32_t device, kp1_curriculum_state* st_dev, const u
   int rc = check_device(device);
   if (rc != KP1_OK) return rc;
   hipLaunchKernelGGL(curriculum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, st_dev, dones, n, steps_per_call);
+  HIP_TRY(kp1::launch_status());
+  return KP1_OK;
+}
+int kp1_curriculum_observe_chunk(int32_t device, kp1_curriculum_state* st_dev, const uint8_t* dones, int32_t n_local, int32_t chunk_steps,
+                                 int32_t world, void* stream) {
+  if (!st_dev || !dones || n_local <= 0 || chunk_steps <= 0 || world <= 0) return fail(KP1_ERR_INVALID, "bad argument to kp1_curriculum_observe_chunk");
+  int rc = check_device(device);
+  if (rc != KP1_OK) return rc;
+  hipLaunchKernelGGL(curriculum_chunk_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, st_dev, dones, n_local, chunk_steps, world, n_local * world);
   HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }

@@ -52,6 +52,14 @@ class PointCurriculum:
         native.check(self.L.kp1_curriculum_observe(self.device.index or 0, self._st, C.c_void_p(dones.data_ptr()), int(dones.numel()),
                                                    int(steps_per_call), C.c_void_p(stream)))
 
+    def observe_chunk(self, dones_all: torch.Tensor, n_local: int, chunk_steps: int, world: int) -> None:
+        """data-parallel rollouts: the all-gathered [world, chunk_steps, n_local] done bytes of a chunk of env steps, replayed in the
+        reference's order (step by step, global env id order inside a step)"""
+        assert dones_all.numel() == world * chunk_steps * n_local and dones_all.dtype == torch.uint8 and dones_all.is_contiguous()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        native.check(self.L.kp1_curriculum_observe_chunk(self.device.index or 0, self._st, C.c_void_p(dones_all.data_ptr()), int(n_local), int(chunk_steps),
+                                                         int(world), C.c_void_p(stream)))
+
     def read(self) -> CurriculumState:
         out = CurriculumState()
         stream = torch.cuda.current_stream(self.device).cuda_stream

@@ -29,6 +29,7 @@ class MlpKernels:
         L.kp1_mlp_adam_step.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, i32, i32, vp]
         L.kp1_mlp_time_kernels.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
         L.kp1_mlp_set_option.argtypes = [vp, i32, i32]
+        L.kp1_mlp_profile_read.argtypes = [vp, vp, vp]
         self.hidden = hidden
         self.device = device
         self.max_batch = int(max_batch)
@@ -60,6 +61,20 @@ class MlpKernels:
     def set_step_count(self, steps: int) -> None:
         """Device-resident optimiser step count (restoring a checkpoint's Adam state)."""
         native.check(self.L.kp1_mlp_set_option(self._h, self.OPT_STEP_COUNT, int(steps)))
+
+    OPT_PROFILE = 4
+    PROFILE_SLOTS = ("mlp_train_tile", "gemm_tn_frag", "grad_finalize", "adam")
+
+    def set_profile(self, on: bool) -> None:
+        """HIP-event pairs around every launch of the optimiser step (eager launches only); read with ``profile_read``."""
+        native.check(self.L.kp1_mlp_set_option(self._h, self.OPT_PROFILE, int(bool(on))))
+
+    def profile_read(self) -> dict[str, dict[str, float]]:
+        """average in-situ duration (us) and launch count of each optimiser-step kernel since the last read"""
+        us = (C.c_float * 4)()
+        cnt = (C.c_int32 * 4)()
+        native.check(self.L.kp1_mlp_profile_read(self._h, C.cast(us, C.c_void_p), C.cast(cnt, C.c_void_p)))
+        return {name: {"us": float(us[i]), "launches": int(cnt[i])} for i, name in enumerate(self.PROFILE_SLOTS)}
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

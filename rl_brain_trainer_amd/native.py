@@ -91,6 +91,7 @@ def load() -> C.CDLL:
     L.kp1_curriculum_create.argtypes = [i32, C.c_double, i32, i32, i32, i32, C.POINTER(vp)]
     L.kp1_curriculum_destroy.argtypes = [i32, vp]
     L.kp1_curriculum_observe.argtypes = [i32, vp, vp, i32, i32, vp]
+    L.kp1_curriculum_observe_chunk.argtypes = [i32, vp, vp, i32, i32, i32, vp]
     L.kp1_curriculum_read.argtypes = [i32, vp, vp, vp]
     L.kp1_bind_stage_ptr.argtypes = [vp, vp]
     L.kp1_set_obs_stride.argtypes = [vp, i32]

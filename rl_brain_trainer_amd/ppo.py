@@ -144,7 +144,13 @@ def gaussian_log_prob(actions: torch.Tensor, mean: torch.Tensor, log_std: torch.
 
 
 class Dist:
-    """torch.distributed glue (backend nccl = RCCL on ROCm, gloo on CPU tests).  world_size 1 = no-ops."""
+    """torch.distributed glue (backend nccl = RCCL on ROCm, gloo on CPU tests).  world_size 1 = no-ops.
+
+    RCCL collectives are captured INSIDE the hipGraphs of the rollout and of the update epoch (``graphs_ok``): with ~100 us of
+    kernels per optimiser step an eagerly launched 650 KB all-reduce would leave the GPU idle for its whole host latency 512 times per
+    iteration.  Whether capture works is probed once per process on a 4-float all-reduce (capture, replay, check the sum); any exception
+    or wrong result selects the eager path on ALL ranks (the verdict is itself all-reduced), a hang is turned into a clear process exit
+    by a watchdog.  ``KP1_DIST_GRAPHS=0`` skips the probe and runs eagerly."""
 
     def __init__(self) -> None:
         import torch.distributed as dist
@@ -153,6 +159,8 @@ class Dist:
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.world_size = dist.get_world_size() if self.enabled else 1
         self.rank = dist.get_rank() if self.enabled else 0
+        self.backend = str(dist.get_backend()) if self.enabled else ""
+        self._graphs_ok: bool | None = None
 
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         if self.enabled:
@@ -166,10 +174,68 @@ class Dist:
         self.dist.all_gather_into_tensor(out, t.contiguous().view(-1))
         return out
 
+    def all_gather_into(self, out: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        """out[world, ...] <- every rank's t (rank-major), into a caller-owned buffer (graph replays need a fixed address)."""
+        if self.enabled:
+            self.dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1))
+        else:
+            out.view(-1).copy_(t.reshape(-1))
+        return out
+
     def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         if self.enabled:
             self.dist.broadcast(t, src)
         return t
+
+    def graphs_ok(self, device: torch.device) -> bool:
+        """True when collectives of this process group can live inside a captured hipGraph (single process: trivially)."""
+        if not self.enabled:
+            return True
+        if self._graphs_ok is None:
+            self._graphs_ok = self._probe_graph_collectives(device)
+        return self._graphs_ok
+
+    def _probe_graph_collectives(self, device: torch.device) -> bool:
+        import os
+        import sys
+        import threading
+
+        ok = self.backend == "nccl" and os.environ.get("KP1_DIST_GRAPHS", "1") != "0"
+        verdict = torch.tensor([1.0 if ok else 0.0], device=device)
+        if ok:
+            buf = torch.full((4,), float(self.rank + 1), device=device)
+            expect = float(self.world_size * (self.world_size + 1) // 2)
+            self.dist.all_reduce(buf.clone())          # communicator fully set up before any capture
+            torch.cuda.synchronize(device)
+
+            def _hung() -> None:
+                print("[kp1] a captured RCCL all-reduce did not complete within 120 s: re-run with KP1_DIST_GRAPHS=0", file=sys.stderr, flush=True)
+                os._exit(3)
+
+            dog = threading.Timer(120.0, _hung)
+            dog.daemon = True
+            dog.start()
+            g, good = None, True
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.dist.all_reduce(buf)
+            except Exception as exc:  # noqa: BLE001 -- capture of a collective is refused in many ways depending on the build
+                print(f"[kp1] rank {self.rank}: RCCL inside hipGraph capture not available ({type(exc).__name__}: {exc}); eager collectives", file=sys.stderr)
+                good = False
+            # a rank whose capture failed never replays: agree (eagerly) that EVERY rank captured before any rank replays
+            captured = torch.tensor([1.0 if good else 0.0], device=device)
+            self.dist.all_reduce(captured, op=self.dist.ReduceOp.MIN)
+            good = bool(captured.item() > 0.5)
+            if good:
+                buf.fill_(float(self.rank + 1))
+                g.replay()
+                torch.cuda.synchronize(device)
+                good = bool(torch.all(buf == expect).item())
+            dog.cancel()
+            verdict.fill_(1.0 if good else 0.0)
+        self.dist.all_reduce(verdict, op=self.dist.ReduceOp.MIN)   # every rank takes the same path
+        return bool(verdict.item() > 0.5)
 
 
 class PPO:
@@ -227,16 +293,52 @@ class PPO:
             self.noise = torch.zeros((N, ACT_DIM), dtype=torch.float32, device=dev)
         elif backend != "torch":
             raise ValueError("backend must be 'hip' or 'torch'")
-        # hipGraph replay of the rollout (T x 5 launches) and of one update epoch: single GPU only (no RCCL inside capture)
-        self.use_graphs = bool(use_graphs and backend == "hip" and not self.dist.enabled)
+        # hipGraph replay of the rollout (T x 3 launches) and of one update epoch.  Data parallel: the RCCL collectives are captured inside
+        # the graphs when the process group allows it (Dist.graphs_ok), else every launch is eager.
+        self.use_graphs = bool(use_graphs and backend == "hip" and self.dist.graphs_ok(self.device))
         self._rollout_graph = None
         self._epoch_graph = None
+        self._rollout_graph_key = None     # (env.launch_args_version, curriculum attached?) the rollout graph was captured with
+        self._epoch_graph_key = None       # hyper-parameters baked into the epoch graph's kernel arguments
+        self._kernels_warm = False         # the rollout kernels have run once (code objects loaded, attributes set)
+        # data parallel: done bytes are exchanged once per `done_chunk` env steps (one all-gather of chunk x N bytes instead of one
+        # latency-bound collective per 45 us env step); the device tracker replays the chunk in the reference's order
+        self.done_chunk = 1
+        if self.dist.enabled:
+            import os as _os
+
+            self.done_chunk = math.gcd(T, max(int(_os.environ.get("KP1_DONE_EXCHANGE_STEPS", "16")), 1))
+            self._done_gather = torch.zeros((self.dist.world_size, self.done_chunk, N), dtype=torch.uint8, device=dev)
         # optional host hook after every env step (done bits of that step, device tensor): what SB3 callbacks' _on_step sees.
         # Setting it makes the rollout eager (a host hook cannot live inside a hipGraph replay).
         self.step_callback = None
         if self.use_graphs:
             self.noise_all = torch.zeros((T, N, ACT_DIM), dtype=torch.float32, device=dev)
             self.perm = torch.zeros(T * N, dtype=torch.int64, device=dev)
+
+    def invalidate_graphs(self) -> None:
+        """Drop the captured hipGraphs: a capture freezes host-side scalars into kernel arguments (env stage / mode / config pointers; learning
+        rate, clip range, ent / vf coefficients, minibatch geometry), so after changing any of them the next rollout / epoch is re-captured.
+        Called automatically when ``env.launch_args_version`` or the PPOConfig fields the epoch graph bakes in have changed."""
+        self._rollout_graph = None
+        self._epoch_graph = None
+
+    def _epoch_key(self) -> tuple:
+        c = self.cfg
+        return (c.learning_rate, c.clip_range, c.ent_coef, c.vf_coef, c.max_grad_norm, c.adam_eps, c.batch_size, c.n_steps, c.normalize_advantage,
+                self.dist.world_size)
+
+    def _curriculum_observe(self, t: int) -> None:
+        """after env step t: feed the done bytes to the device tracker (single process: every step; data parallel: once per chunk)"""
+        if self.curriculum is None:
+            return
+        if not self.dist.enabled:
+            self.curriculum.observe(self.done_buf[t], self.n_envs)
+            return
+        c = self.done_chunk
+        if (t + 1) % c == 0:
+            self.dist.all_gather_into(self._done_gather, self.done_buf[t + 1 - c:t + 1])
+            self.curriculum.observe_chunk(self._done_gather, self.n_envs, c, self.dist.world_size)
 
     # ------------------------------------------------------------------ PPO.load
     def load_checkpoint(self, path: str, *, restore_optimizer: bool = True, restore_timesteps: bool = False,
@@ -361,8 +463,10 @@ class PPO:
         graph_rollout = self.use_graphs and self.step_callback is None
         if graph_rollout:
             self.noise_all.normal_(generator=self.gen)
-            if self._rollout_graph is None:
+            key = (getattr(env, "launch_args_version", 0), self.curriculum is not None)
+            if self._rollout_graph is None or self._rollout_graph_key != key:
                 self._capture_rollout()
+                self._rollout_graph_key = key
             self._rollout_graph.replay()
         for t in range(0 if not graph_rollout else T, T):
             if self._mlp is not None:
@@ -379,11 +483,11 @@ class PPO:
                 self.val_buf[t].copy_(value)
                 torch.clamp(action, -1.0, 1.0, out=self.clip_act)
             env.step_into(self.clip_act, self.obs_buf[t + 1], self.rew_buf[t], self.done_buf[t], self.term_obs_buf[t], True)
-            if self.curriculum is not None:
-                dones = self.dist.all_gather_bytes(self.done_buf[t])
-                self.curriculum.observe(dones, N * world)
+            self._curriculum_observe(t)
             if self.step_callback is not None:
                 self.step_callback(self.done_buf[t])
+        if not graph_rollout:
+            self._kernels_warm = True
         self.num_timesteps += T * N * world
         self._bootstrap_truncated()
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -404,28 +508,33 @@ class PPO:
         self._mlp.forward(self.obs_buf[t], noise=self.noise_all[t], value=self.val_buf[t], action=self.act_buf[t],
                           clipped=self.clip_act, log_prob=self.logp_buf[t])
         self.env.step_into(self.clip_act, self.obs_buf[t + 1], self.rew_buf[t], self.done_buf[t], self.term_obs_buf[t], True)
-        if self.curriculum is not None:
-            self.curriculum.observe(self.done_buf[t], self.n_envs)
+        self._curriculum_observe(t)
 
     def _capture_rollout(self) -> None:
-        """Record the T-step rollout (policy forward, env step, curriculum tracker) once; every later rollout is one replay."""
+        """Record the T-step rollout (policy forward, env step, curriculum tracker; data parallel: the done-byte all-gather of every chunk)
+        once; every later rollout is one replay.  The kernels must have run once before a capture (code objects loaded, attributes set).  At
+        the very start that is a warm-up step followed by a fresh reset (the episodes have not begun); a RE-capture in the middle of
+        training (an env setter or a hyper-parameter changed, a step callback was removed) finds them warm from the rollouts already done and
+        leaves the running episodes untouched."""
         T = self.cfg.n_steps
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):  # warm-up on the side stream (sets kernel attributes, loads code objects)
-            self.env.use_current_stream()
-            self._mlp.forward(self.obs_buf[0], noise=self.noise_all[0], value=self.val_buf[0], action=self.act_buf[0],
-                              clipped=self.clip_act, log_prob=self.logp_buf[0])
-            self.env.step_into(self.clip_act, self.obs_buf[1], self.rew_buf[0], self.done_buf[0], self.term_obs_buf[0], True)
-            if self.curriculum is not None:
-                self.curriculum.observe(self.done_buf[0].zero_(), 0)
-            # the warm-up moved every env one step: start the episodes again (one extra reset() draw per env stream)
-            self.env.use_current_stream()
-            self.obs_buf[0].copy_(self.env.reset())
-        torch.cuda.current_stream(self.device).wait_stream(side)
+        if not self._kernels_warm:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                self.env.use_current_stream()
+                self._mlp.forward(self.obs_buf[0], noise=self.noise_all[0], value=self.val_buf[0], action=self.act_buf[0],
+                                  clipped=self.clip_act, log_prob=self.logp_buf[0])
+                self.env.step_into(self.clip_act, self.obs_buf[1], self.rew_buf[0], self.done_buf[0], self.term_obs_buf[0], True)
+                if self.curriculum is not None:
+                    self.curriculum.observe(self.done_buf[0].zero_(), 0)   # also loads the module the chunk form of the tracker lives in
+                # the warm-up moved every env one step: start the episodes again (one extra reset() draw per env stream)
+                self.env.use_current_stream()
+                self.obs_buf[0].copy_(self.env.reset())
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            self._kernels_warm = True
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local" if self.dist.enabled else "global"):
             self.env.use_current_stream()
             for t in range(T):
                 self._rollout_step_hip(t)
@@ -433,9 +542,11 @@ class PPO:
         self._rollout_graph = g
 
     def _capture_epoch(self, obs, act, old_logp, adv, ret, total: int, local_bs: int) -> None:
+        """one update epoch = advantage statistics of all minibatches (+ ONE all-reduce of them), then per minibatch: tile kernel, weight
+        gradients, finalize, [flat gradient all-reduce, sum of squares], Adam -- captured with the collectives inside"""
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(self.device)
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local" if self.dist.enabled else "global"):
             mb_stats = self._epoch_adv_stats(adv, self.perm, total, local_bs)
             for i, start in enumerate(range(0, total, local_bs)):
                 self._hip_minibatch_step(obs, self.perm[start:start + local_bs], act, old_logp, adv, ret, device_step=True,
@@ -461,6 +572,8 @@ class PPO:
         for _epoch in range(cfg.n_epochs):
             if self.use_graphs:
                 torch.randperm(total, device=self.device, generator=self.gen, out=self.perm)
+                if self._epoch_graph is not None and self._epoch_graph_key != self._epoch_key():
+                    self._epoch_graph = None     # a hyper-parameter baked into the captured kernel arguments changed: capture again
                 if self._epoch_graph is None:
                     # one eager epoch first (warm-up + it is a real epoch), then capture for the following ones
                     if not self._epoch_warm:
@@ -473,6 +586,7 @@ class PPO:
                             self.adam_t += 1
                         continue
                     self._capture_epoch(obs, act, old_logp, adv, ret, total, local_bs)
+                    self._epoch_graph_key = self._epoch_key()
                 self._epoch_graph.replay()
                 n_updates += (total + local_bs - 1) // local_bs
                 self.adam_t += (total + local_bs - 1) // local_bs

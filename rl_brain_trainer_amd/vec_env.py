@@ -67,6 +67,9 @@ class ArmKinematicVecEnv:
         self._mode_name = config.mode_name
         self.obs_stride = kcfg.OBS_DIM
         self._components = False
+        # bumped by every setter whose value a captured hipGraph of kp1_step would have frozen into kernel arguments (stage, mode, config,
+        # reward-component switch, handoff buffer, observation pitch): ppo.PPO re-captures its rollout graph when it changes
+        self.launch_args_version = 0
         if reward_components:
             self.enable_reward_components(True)
 
@@ -85,6 +88,7 @@ class ArmKinematicVecEnv:
     # ------------------------------------------------------------------ reference API
     def set_curriculum_stage(self, stage_index: int) -> None:
         native.check(self.L.kp1_set_stage(self._handle, int(stage_index)))
+        self.launch_args_version += 1
 
     def get_curriculum_stage(self) -> int:
         out = C.c_int32()
@@ -96,6 +100,7 @@ class ArmKinematicVecEnv:
             raise ValueError(f"Unsupported policy mode '{mode_name}'")
         native.check(self.L.kp1_set_mode(self._handle, kcfg.MODE_NAMES[mode_name]))
         self._mode_name = mode_name
+        self.launch_args_version += 1
 
     def env_method(self, name: str, *args: Any) -> list[Any]:
         """VecEnv.env_method: the trainers only broadcast (callbacks.py:55,69,162)."""
@@ -125,11 +130,21 @@ class ArmKinematicVecEnv:
             if key in stage_updates:
                 setattr(c.env, key, float(stage_updates[key]))
         native.check(self.L.kp1_update_config(self._handle, C.byref(c)))
+        self.launch_args_version += 1
+
+    def set_handoff_states(self, states: list[dict[str, Any]]) -> None:
+        """Replace the handoff-state buffer dock resets draw from (reset_samplers.py:131-165).  The old device buffer is freed: a
+        rollout graph captured before this call must not be replayed again (PPO checks launch_args_version)."""
+        self.config.handoff_states = list(states)
+        arr = self.config.handoff_array()
+        native.check(self.L.kp1_set_handoff_states(self._handle, C.cast(arr, C.c_void_p), len(self.config.handoff_states)))
+        self.launch_args_version += 1
 
     def set_obs_stride(self, stride: int) -> None:
         """Row pitch of every observation buffer handed to reset/step (56, or 64 = zero-padded for the MFMA GEMMs)."""
         native.check(self.L.kp1_set_obs_stride(self._handle, int(stride)))
         self.obs_stride = int(stride)
+        self.launch_args_version += 1
         self.obs = torch.zeros((self.n_envs, self.obs_stride), dtype=torch.float32, device=self.device)
         self.terminal_obs = torch.zeros_like(self.obs)
 
@@ -233,6 +248,7 @@ class ArmKinematicVecEnv:
     def enable_reward_components(self, enable: bool = True) -> None:
         native.check(self.L.kp1_enable_reward_components(self._handle, int(enable)))
         self._components = bool(enable)
+        self.launch_args_version += 1
 
     def reward_components(self) -> tuple[list[str], torch.Tensor]:
         ptr, n = C.c_void_p(), C.c_int32()
