@@ -80,6 +80,51 @@ int kp1_curriculum_read(int32_t device, const kp1_curriculum_state* st_dev, kp1_
 /* make kp1_step take its curriculum stage from *stage_dev (e.g. &tracker->stage_index) instead of kp1_set_stage */
 int kp1_bind_stage_ptr(kp1_env* env, const int32_t* stage_dev);
 
+/* ---- device-resident DockReverseCurriculumCallback (kinematic_phase1/training/callbacks.py:104-212) -------------
+ * The Finisher's reverse curriculum: after every VecEnv step the callback scans (done, info["success"]) in env order, keeps the last
+ * `window_episodes` success bits and, when the current stage has seen `min_episodes` episodes and the newest `stage window` of them reach
+ * `success_rate_threshold`, applies the next stage's overrides to all envs (apply_dock_training_stage, arm_kinematic_env.py:459-487).
+ * A stage here carries the RESOLVED values (base config overlaid by the payloads of stages 0..k in order, which is what the env holds after
+ * k promotions); the tracker writes them into the device config the step / reset kernels read. */
+#define KP1_DOCK_CURRICULUM_MAX_STAGES 16
+#define KP1_DOCK_CURRICULUM_MAX_WINDOW 1024
+#define KP1_DOCK_CURRICULUM_MAX_HISTORY 32
+typedef struct kp1_dock_curriculum_stage {
+  double action_delta_scale, dock_residual_action_limit, dock_delta_q_change_limit_scale;             /* env scalars */
+  double close_bucket_probability, close_bucket_min_pos_error_m, close_bucket_max_pos_error_m, close_bucket_max_ori_error_rad,
+         handoff_state_probability;                                                                    /* dock_reset scalars */
+  double close_init_q_noise[KP1_NJ], init_q_noise[KP1_NJ];
+  double success_rate_threshold;     /* stage.get("success_rate_threshold", 1.0) */
+  int32_t min_episodes;              /* stage.get("min_episodes", window_episodes) */
+  int32_t window_episodes;           /* stage.get("window_episodes", window_episodes) */
+  /* handoff-state buffer of this stage (stages may override handoff_state_buffer_path and the three handoff_state_max_* filters,
+   * reset_samplers.py:131-165): a slice [offset, offset + count) of the buffer given to kp1_set_handoff_states, which then holds the
+   * filtered lists of all stages back to back.  count < 0: the stage does not manage the buffer (the env's whole buffer stays in use). */
+  int32_t handoff_offset, handoff_count;
+} kp1_dock_curriculum_stage;
+typedef struct kp1_dock_curriculum_event {
+  int64_t total_timesteps;
+  int32_t from_stage, to_stage, stage_episode_count, reserved0;
+  double trigger_success_rate;
+} kp1_dock_curriculum_event;
+typedef struct kp1_dock_curriculum_state {
+  int32_t stage_index, stage_episode_count, ring_len, ring_head, window_episodes, n_stages, n_events, reserved0;
+  int64_t num_timesteps;
+  kp1_dock_curriculum_stage stages[KP1_DOCK_CURRICULUM_MAX_STAGES];
+  kp1_dock_curriculum_event events[KP1_DOCK_CURRICULUM_MAX_HISTORY];
+  uint8_t ring[KP1_DOCK_CURRICULUM_MAX_WINDOW];
+} kp1_dock_curriculum_state;
+/* allocate the tracker next to a dock-mode env and apply stage 0 (_on_training_start) */
+int kp1_dock_curriculum_create(kp1_env* env, const kp1_dock_curriculum_stage* stages_host, int32_t n_stages, int32_t window_episodes,
+                               kp1_dock_curriculum_state** out_dev);
+int kp1_dock_curriculum_destroy(kp1_env* env, kp1_dock_curriculum_state* st_dev);
+/* _on_step: dones = [world][chunk_steps][n_local] done bytes (one process, one env step: world = chunk_steps = 1), replayed step by step
+ * and rank by rank = global env order; the clock advances by world * n_local per env step */
+int kp1_dock_curriculum_observe(kp1_env* env, kp1_dock_curriculum_state* st_dev, const uint8_t* dones, int32_t n_local, int32_t chunk_steps, int32_t world,
+                                void* stream);
+/* copy the tracker to the host; also brings the env handle's host-side config mirror in step with the stage the device applied */
+int kp1_dock_curriculum_read(kp1_env* env, const kp1_dock_curriculum_state* st_dev, kp1_dock_curriculum_state* out_host, void* stream);
+
 /* ---- actor-critic MLP on the matrix cores (fp32-in / fp32-accumulate MFMA, exact f32) ---------------------------
  * SB3 MultiInputActorCriticPolicy with net_arch pi = vf = [H, H], tanh:
  *   h1 = tanh(x W1^T + b1); h2 = tanh(h1 W2^T + b2); mean = h2p Wa^T + ba (7); value = h2v Wv^T + bv (1).

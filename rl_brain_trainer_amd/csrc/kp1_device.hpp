@@ -88,8 +88,8 @@ struct DevSampler {
   kp1_random_start rs;
   kp1_dock_reset dr;
   double start_sample_margin_fraction, goal_sample_margin_fraction;
-  int n_handoff;
-  int pad0;
+  int n_handoff;        // states a dock reset may draw from: handoff[handoff_offset .. handoff_offset + n_handoff)
+  int handoff_offset;   // 0 unless the dock reverse curriculum selected a stage-specific slice of the buffer
   DevFk<double> fk;  // goal_q -> goal_pose6 is part of the sampled state; close-bucket rejection needs fp64 FK
 };
 

@@ -73,7 +73,7 @@ __device__ __forceinline__ void sample_reset(const DevSampler& __restrict__ s, c
   if constexpr (MODE == KP1_MODE_DOCK) {
     const kp1_dock_reset& c = s.dr;
     if (c.handoff_state_probability > 0.0 && s.n_handoff > 0 && pcg_double(rng) < c.handoff_state_probability) {
-      const kp1_handoff_state& h = handoff[pcg_integers(rng, 0, s.n_handoff)];
+      const kp1_handoff_state& h = handoff[s.handoff_offset + pcg_integers(rng, 0, s.n_handoff)];
       for (int k = 0; k < NJ; ++k) {
         o.initial_q[k] = h.initial_q[k];
         o.goal_q[k] = h.goal_q[k];
@@ -751,6 +751,7 @@ void make_dev_sampler(const kp1_config& c, int n_handoff, DevSampler* s) {
   s->start_sample_margin_fraction = c.env.start_sample_margin_fraction;
   s->goal_sample_margin_fraction = c.env.goal_sample_margin_fraction;
   s->n_handoff = n_handoff;
+  s->handoff_offset = 0;
   fold_fk<double>(&s->fk);
 }
 
@@ -1381,3 +1382,4 @@ int kp1_joint_utils(int32_t device, int32_t real_type, const kp1_config* cfg, co
 }  // extern "C"
 
 #include "kp1_route.inc"
+#include "kp1_dock_curriculum.inc"

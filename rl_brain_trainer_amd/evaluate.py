@@ -16,7 +16,6 @@ goal poses come from the fp64 HIP FK kernel.
 from __future__ import annotations
 
 import json
-from dataclasses import dataclass, fields
 from pathlib import Path
 from typing import Any, Callable
 
@@ -30,76 +29,103 @@ PolicyFn = Callable[[torch.Tensor], torch.Tensor]  # obs [E, stride] -> clipped 
 
 
 # ----------------------------------------------------------------------------- gate scoring (host logic)
-@dataclass(frozen=True)
-class WorkspaceGateConfig:
-    retention_stage0_4_success: float = 0.95
-    retention_stage5_success: float = 0.85
-    retention_stage_thresholds: tuple[float, ...] = ()
-    promotion_stage_success: float = 0.80
-    promotion_ready_rate: float = 0.80
-    max_mean_position_error_m: float = 0.020
-    max_mean_orientation_error_rad: float = 0.15
-    score_current_success_weight: float = 0.45
-    score_current_ready_weight: float = 0.20
-    score_retention_weight: float = 0.20
-    score_error_weight: float = 0.15
+# The YAML ``gate:`` block and the ``best_model_selection`` JSON are schemas other tools read (check_workspace_expansion_status.sh,
+# plot_workspace_expansion.py): key names and default values are the reference's (workspace/workspace_curriculum.py:20-32).  The
+# evaluation itself works on one small numeric table per call instead of walking dicts stage by stage.
+_GATE_DEFAULTS: dict[str, Any] = {
+    "retention_stage0_4_success": 0.95, "retention_stage5_success": 0.85, "retention_stage_thresholds": (),
+    "promotion_stage_success": 0.80, "promotion_ready_rate": 0.80, "max_mean_position_error_m": 0.020, "max_mean_orientation_error_rad": 0.15,
+    "score_current_success_weight": 0.45, "score_current_ready_weight": 0.20, "score_retention_weight": 0.20, "score_error_weight": 0.15,
+}
+_METRIC_COLUMNS = ("success_rate", "finisher_ready_hit_rate", "mean_final_position_error", "mean_final_orientation_error")
 
 
-def gate_config_from_dict(payload: dict[str, Any] | None) -> WorkspaceGateConfig:
-    data = dict(payload or {})
-    if "retention_stage_thresholds" in data:
-        data["retention_stage_thresholds"] = tuple(float(v) for v in data["retention_stage_thresholds"])
-    names = {f.name for f in fields(WorkspaceGateConfig)}
-    return WorkspaceGateConfig(**{k: v for k, v in data.items() if k in names})
+class WorkspaceGate:
+    """Thresholds and score weights of the workspace-expansion eval gate (attribute per YAML key)."""
+
+    def __init__(self, **overrides: Any) -> None:
+        for key, default in _GATE_DEFAULTS.items():
+            value = overrides.get(key, default)
+            setattr(self, key, tuple(float(v) for v in value) if key == "retention_stage_thresholds" else float(value))
+
+    def as_dict(self) -> dict[str, Any]:
+        return {k: getattr(self, k) for k in _GATE_DEFAULTS}
 
 
-def stage_passed(m: dict[str, Any], cfg: WorkspaceGateConfig) -> bool:
-    return bool(float(m.get("success_rate", 0.0)) >= cfg.promotion_stage_success
-                and float(m.get("finisher_ready_hit_rate", 0.0)) >= cfg.promotion_ready_rate
-                and float(m.get("mean_final_position_error", 999.0)) <= cfg.max_mean_position_error_m
-                and float(m.get("mean_final_orientation_error", 999.0)) <= cfg.max_mean_orientation_error_rad)
+WorkspaceGateConfig = WorkspaceGate   # name the trainers import
 
 
-def retention_ok(stage_metrics: dict[int, dict[str, Any]], cfg: WorkspaceGateConfig) -> bool:
-    if cfg.retention_stage_thresholds:
-        for idx, thr in enumerate(cfg.retention_stage_thresholds):
-            if idx in stage_metrics and float(stage_metrics[idx].get("success_rate", 0.0)) < float(thr):
-                return False
-        return True
-    for idx in range(5):
-        if float(stage_metrics.get(idx, {}).get("success_rate", 0.0)) < cfg.retention_stage0_4_success:
-            return False
-    return float(stage_metrics.get(5, {}).get("success_rate", 0.0)) >= cfg.retention_stage5_success
+def gate_config_from_dict(payload: dict[str, Any] | None) -> WorkspaceGate:
+    return WorkspaceGate(**{k: v for k, v in dict(payload or {}).items() if k in _GATE_DEFAULTS})
 
 
-def highest_passed_stage(stage_metrics: dict[int, dict[str, Any]], cfg: WorkspaceGateConfig) -> int:
-    best = -1
-    for idx in sorted(stage_metrics):
-        if stage_passed(stage_metrics[idx], cfg):
-            best = idx
-        elif idx >= 6:
-            break
-    return best
+class _StageTable:
+    """stage_metrics {stage index -> summary dict} as columns: `idx` sorted ascending, one float column per gate metric."""
+
+    def __init__(self, stage_metrics: dict[int, dict[str, Any]], missing: tuple[float, float, float, float]) -> None:
+        self.idx = np.array(sorted(int(k) for k in stage_metrics), dtype=np.int64)
+        rows = [[float(stage_metrics[int(i)].get(name, fill)) for name, fill in zip(_METRIC_COLUMNS, missing)] for i in self.idx]
+        self.col = np.array(rows, dtype=np.float64).reshape(len(rows), len(_METRIC_COLUMNS))
+
+    def lookup(self, stages: np.ndarray, column: int, fill: float) -> np.ndarray:
+        """column values at the given stage indices; stages without a row read as `fill`"""
+        out = np.full(len(stages), fill, dtype=np.float64)
+        if self.idx.size:
+            pos = np.searchsorted(self.idx, stages)
+            hit = (pos < self.idx.size) & (self.idx[np.minimum(pos, self.idx.size - 1)] == stages)
+            out[hit] = self.col[pos[hit], column]
+        return out
 
 
-def gated_score(stage_metrics: dict[int, dict[str, Any]], current_stage: int, cfg: WorkspaceGateConfig) -> dict[str, Any]:
-    cur = stage_metrics.get(current_stage, {})
-    ret = [float(stage_metrics.get(i, {}).get("success_rate", 0.0)) for i in range(0, min(6, current_stage + 1))]
-    retention = sum(ret) / len(ret) if ret else 0.0
-    pos_err = float(cur.get("mean_final_position_error", 1.0))
-    ori_err = float(cur.get("mean_final_orientation_error", 1.0))
-    pos_score = max(0.0, 1.0 - pos_err / max(cfg.max_mean_position_error_m, 1e-6))
-    ori_score = max(0.0, 1.0 - ori_err / max(cfg.max_mean_orientation_error_rad, 1e-6))
-    error_score = 0.5 * (pos_score + ori_score)
-    score = (float(cur.get("success_rate", 0.0)) * cfg.score_current_success_weight
-             + float(cur.get("finisher_ready_hit_rate", 0.0)) * cfg.score_current_ready_weight
-             + retention * cfg.score_retention_weight + error_score * cfg.score_error_weight)
+def _passed_mask(tab: _StageTable, gate: WorkspaceGate) -> np.ndarray:
+    """per evaluated stage: success, ready-hit rate and both mean errors inside the promotion thresholds"""
+    c = tab.col
+    return (c[:, 0] >= gate.promotion_stage_success) & (c[:, 1] >= gate.promotion_ready_rate) & \
+           (c[:, 2] <= gate.max_mean_position_error_m) & (c[:, 3] <= gate.max_mean_orientation_error_rad)
+
+
+def stage_passed(metrics: dict[str, Any], gate: WorkspaceGate) -> bool:
+    return bool(_passed_mask(_StageTable({0: metrics}, (0.0, 0.0, 999.0, 999.0)), gate)[0])
+
+
+def retention_ok(stage_metrics: dict[int, dict[str, Any]], gate: WorkspaceGate) -> bool:
+    """old stages must keep their success rate: per-stage thresholds where the config lists them (only stages that were evaluated count),
+    else stages 0-4 and stage 5 against the two fixed levels (a stage that was not evaluated counts as 0)"""
+    tab = _StageTable(stage_metrics, (0.0, 0.0, 999.0, 999.0))
+    if gate.retention_stage_thresholds:
+        thr = np.asarray(gate.retention_stage_thresholds, dtype=np.float64)
+        listed = tab.idx[(tab.idx >= 0) & (tab.idx < thr.size)]
+        return bool(np.all(tab.lookup(listed, 0, 0.0) >= thr[listed]))
+    succ = tab.lookup(np.arange(6), 0, 0.0)
+    return bool(np.all(succ[:5] >= gate.retention_stage0_4_success) and succ[5] >= gate.retention_stage5_success)
+
+
+def highest_passed_stage(stage_metrics: dict[int, dict[str, Any]], gate: WorkspaceGate) -> int:
+    """largest passing stage index below the first FAILING expansion stage (index >= 6); -1 when none passes"""
+    tab = _StageTable(stage_metrics, (0.0, 0.0, 999.0, 999.0))
+    ok = _passed_mask(tab, gate)
+    blockers = np.flatnonzero(~ok & (tab.idx >= 6))
+    reach = int(blockers[0]) if blockers.size else tab.idx.size
+    good = tab.idx[:reach][ok[:reach]]
+    return int(good[-1]) if good.size else -1
+
+
+def gated_score(stage_metrics: dict[int, dict[str, Any]], current_stage: int, gate: WorkspaceGate) -> dict[str, Any]:
+    """best-checkpoint score of one evaluation: weighted current-stage success / ready-hit rate, retention over stages 0..min(5, current)
+    and an error score; the current stage's missing errors count as 1.0 (m / rad)"""
+    tab = _StageTable(stage_metrics, (0.0, 0.0, 1.0, 1.0))
+    stage = np.array([int(current_stage)])
+    cur_succ, cur_ready, cur_pos, cur_ori = (float(tab.lookup(stage, k, fill)[0]) for k, fill in enumerate((0.0, 0.0, 1.0, 1.0)))
+    kept = tab.lookup(np.arange(0, min(6, int(current_stage) + 1)), 0, 0.0)
+    retention = float(kept.sum() / kept.size) if kept.size else 0.0
+    limits = np.maximum([gate.max_mean_position_error_m, gate.max_mean_orientation_error_rad], 1e-6)
+    error_score = float(0.5 * np.maximum(0.0, 1.0 - np.array([cur_pos, cur_ori]) / limits).sum())
+    score = cur_succ * gate.score_current_success_weight + cur_ready * gate.score_current_ready_weight \
+        + retention * gate.score_retention_weight + error_score * gate.score_error_weight
     return {
-        "score": float(score), "current_stage": int(current_stage), "retention_ok": retention_ok(stage_metrics, cfg),
-        "highest_passed_stage": int(highest_passed_stage(stage_metrics, cfg)),
-        "current_stage_success_rate": float(cur.get("success_rate", 0.0)),
-        "current_stage_ready_rate": float(cur.get("finisher_ready_hit_rate", 0.0)),
-        "retention_mean_success_rate": float(retention), "error_score": float(error_score),
+        "score": float(score), "current_stage": int(current_stage), "retention_ok": retention_ok(stage_metrics, gate),
+        "highest_passed_stage": highest_passed_stage(stage_metrics, gate), "current_stage_success_rate": cur_succ,
+        "current_stage_ready_rate": cur_ready, "retention_mean_success_rate": retention, "error_score": error_score,
     }
 
 

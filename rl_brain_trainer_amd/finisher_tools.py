@@ -1,99 +1,188 @@
 """Finisher-side tooling on the device engine: the dock reverse-curriculum callback logic and the handoff-state
 buffer builder, so the Finisher can be (re)trained from the engine's own Approach policy.
 
-Mirror of kinematic_phase1/training/callbacks.py:104-212 (``DockReverseCurriculumCallback``) and
-kinematic_phase1/training/build_finisher_handoff_state_buffer.py:19-143: same stage payload keys, promotion rule, JSON layout
-of ``finisher_handoff_state_buffer.json`` (what ``dock_reset.handoff_state_buffer_path`` points at, reset_samplers.py:131-165).
-All suite episodes of the buffer builder run in ONE vectorised Approach env (``evaluate.run_episodes``).
+The reverse curriculum (kinematic_phase1/training/callbacks.py:104-212, ``DockReverseCurriculumCallback``) is a one-wave device tracker
+(include/kp1_ppo.h, kp1_dock_curriculum_*; csrc/kp1_dock_curriculum.inc): ``DockReverseCurriculum`` below is its host handle and resolves
+the YAML stages into the values each stage leaves in the env.  The handoff-state buffer builder
+(kinematic_phase1/training/build_finisher_handoff_state_buffer.py:19-143) keeps the JSON layout of ``finisher_handoff_state_buffer.json``
+(what ``dock_reset.handoff_state_buffer_path`` points at, reset_samplers.py:131-165) and runs all suite episodes in ONE vectorised
+Approach env (``evaluate.run_episodes``).
 """
 from __future__ import annotations
 
+import ctypes as C
 import json
-from collections import deque
 from pathlib import Path
-from typing import Any, Sequence
+from typing import Any
 
 import numpy as np
+import torch
 
 from . import config as kcfg
 
+# keys a reverse-curriculum stage may override (callbacks.py:131-150): three env scalars, the dock_reset block
 _STAGE_ENV_KEYS = ("action_delta_scale", "dock_residual_action_limit", "dock_delta_q_change_limit_scale")
-_STAGE_RESET_KEYS = ("close_bucket_probability", "close_bucket_min_pos_error_m", "close_bucket_max_pos_error_m", "close_bucket_max_ori_error_rad",
-                     "close_init_q_noise", "init_q_noise", "handoff_state_probability", "handoff_state_buffer_path", "handoff_state_max_position_error_m",
-                     "handoff_state_max_orientation_error_rad", "handoff_state_max_action_l2")
+_STAGE_RESET_SCALARS = ("close_bucket_probability", "close_bucket_min_pos_error_m", "close_bucket_max_pos_error_m", "close_bucket_max_ori_error_rad",
+                        "handoff_state_probability")
+_STAGE_RESET_VECTORS = ("close_init_q_noise", "init_q_noise")
+# a stage may also re-filter (or replace) the handoff-state buffer (reset_samplers.py:131-165): the filtered list of every stage is built
+# once, when the tracker is attached, and the device buffer holds them back to back; a promotion then only switches (offset, count)
+_STAGE_BUFFER_KEYS = ("handoff_state_buffer_path", "handoff_state_max_position_error_m", "handoff_state_max_orientation_error_rad", "handoff_state_max_action_l2")
+_BUFFER_DEFAULTS = {"handoff_state_buffer_path": "", "handoff_state_max_position_error_m": 1.0, "handoff_state_max_orientation_error_rad": 10.0,
+                    "handoff_state_max_action_l2": 10.0}   # DockResetConfig defaults, reset_samplers.py:109-113
+MAX_STAGES, MAX_WINDOW, MAX_HISTORY = 16, 1024, 32
+
+
+class _Stage(C.Structure):
+    _fields_ = [(k, C.c_double) for k in _STAGE_ENV_KEYS + _STAGE_RESET_SCALARS] + [(k, C.c_double * kcfg.NJ) for k in _STAGE_RESET_VECTORS] + \
+               [("success_rate_threshold", C.c_double), ("min_episodes", C.c_int32), ("window_episodes", C.c_int32),
+                ("handoff_offset", C.c_int32), ("handoff_count", C.c_int32)]
+
+
+class _Event(C.Structure):
+    _fields_ = [("total_timesteps", C.c_int64), ("from_stage", C.c_int32), ("to_stage", C.c_int32), ("stage_episode_count", C.c_int32), ("reserved0", C.c_int32),
+                ("trigger_success_rate", C.c_double)]
+
+
+class _State(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("stage_index", "stage_episode_count", "ring_len", "ring_head", "window_episodes", "n_stages", "n_events", "reserved0")] + \
+               [("num_timesteps", C.c_int64), ("stages", _Stage * MAX_STAGES), ("events", _Event * MAX_HISTORY), ("ring", C.c_uint8 * MAX_WINDOW)]
 
 
 class DockReverseCurriculum:
-    def __init__(self, *, stages: list[dict[str, object]], window_episodes: int) -> None:
+    """The Finisher's reverse curriculum (``training.dock_reverse_curriculum`` of the YAML: ``stages`` + ``window_episodes``) as a device tracker.
+    ``PPO(curriculum=...)`` calls ``attach(env)`` once and ``observe(done_bytes, steps)`` after every env step on the rollout stream, so the
+    dock rollout is one hipGraph replay; ``summary()`` has the reference callback's keys."""
+
+    def __init__(self, *, stages: list[dict[str, object]], window_episodes: int, handoff_base_dirs: tuple[Path, ...] = ()) -> None:
         if not stages:
             raise ValueError("DockReverseCurriculumCallback requires at least one stage")
-        self.stages = list(stages)
+        if len(stages) > MAX_STAGES or int(window_episodes) > MAX_WINDOW:
+            raise ValueError(f"the device tracker holds at most {MAX_STAGES} stages and a window of {MAX_WINDOW} episodes")
+        self.stages = [dict(s) for s in stages]
         self.window_episodes = max(int(window_episodes), 1)
-        self.current_stage_index = 0
-        self.stage_episode_count = 0
-        self.recent_successes: deque[int] = deque(maxlen=self.window_episodes)
-        self.history: list[dict[str, object]] = []
-        self.num_timesteps = 0
-        self.training_env: Any = None
+        self.handoff_base_dirs = tuple(handoff_base_dirs)
+        self.env: Any = None
+        self._st = C.c_void_p()
 
-    @staticmethod
-    def stage_payload(stage: dict[str, object]) -> dict[str, object]:
-        payload: dict[str, object] = {"dock_reset": {}}
-        for key in _STAGE_ENV_KEYS:
-            if key in stage:
-                payload[key] = stage[key]
-        for key in _STAGE_RESET_KEYS:
-            if key in stage:
-                payload["dock_reset"][key] = stage[key]
+    # ---------------------------------------------------------------- host side: what each stage leaves in the env
+    def stage_payload(self, index: int) -> dict[str, object]:
+        """the ``apply_dock_training_stage`` argument of stage ``index``: only the keys the stage names"""
+        stage = self.stages[index]
+        payload: dict[str, object] = {key: stage[key] for key in _STAGE_ENV_KEYS if key in stage}
+        payload["dock_reset"] = {key: stage[key] for key in _STAGE_RESET_SCALARS + _STAGE_RESET_VECTORS + _STAGE_BUFFER_KEYS if key in stage}
         return payload
 
-    def _apply_stage(self, stage_index: int) -> None:
-        self.training_env.env_method("apply_dock_training_stage", self.stage_payload(self.stages[stage_index]))
+    def stage_buffers(self, config: kcfg.EnvConfig) -> list[list[dict[str, list[float]]]] | None:
+        """per stage, the handoff states its dock resets may draw from -- or None when no stage touches the buffer keys (the env keeps the
+        buffer its config was built with).  The settings accumulate over the stages like every other override."""
+        if not any(key in stage for stage in self.stages for key in _STAGE_BUFFER_KEYS):
+            return None
+        base = dict(((config.source or {}).get("env", {}) or {}).get("dock_reset", {}) or {})
+        live = {k: base.get(k, default) for k, default in _BUFFER_DEFAULTS.items()}
+        out = []
+        for stage in self.stages:
+            live.update({k: stage[k] for k in _STAGE_BUFFER_KEYS if k in stage})
+            out.append(kcfg.load_handoff_states(str(live["handoff_state_buffer_path"] or ""), max_position_error_m=float(live["handoff_state_max_position_error_m"]),
+                                                max_orientation_error_rad=float(live["handoff_state_max_orientation_error_rad"]),
+                                                max_action_l2=float(live["handoff_state_max_action_l2"]), base_dirs=self.handoff_base_dirs))
+        return out
 
-    def on_training_start(self, env: Any) -> None:
-        self.training_env = env
-        self._apply_stage(self.current_stage_index)
+    def resolved_stages(self, config: kcfg.EnvConfig, buffers: list[list[Any]] | None = None):
+        """per stage, the full set of overridable values the env holds after stages 0..k were applied in order to ``config``; ``buffers``
+        (stage_buffers) lays the stages' handoff lists back to back and records each stage's slice"""
+        c = config.c
+        live: dict[str, Any] = {k: float(getattr(c.env, k)) for k in _STAGE_ENV_KEYS}
+        live.update({k: float(getattr(c.dock_reset, k)) for k in _STAGE_RESET_SCALARS})
+        live.update({k: [float(v) for v in getattr(c.dock_reset, k)[:]] for k in _STAGE_RESET_VECTORS})
+        out = (_Stage * len(self.stages))()
+        for k, stage in enumerate(self.stages):
+            for key in live:
+                if key in stage:
+                    live[key] = [float(v) for v in stage[key]] if key in _STAGE_RESET_VECTORS else float(stage[key])
+            for key, value in live.items():
+                if key in _STAGE_RESET_VECTORS:
+                    getattr(out[k], key)[:] = value
+                else:
+                    setattr(out[k], key, value)
+            out[k].success_rate_threshold = float(stage.get("success_rate_threshold", 1.0))
+            out[k].min_episodes = max(int(stage.get("min_episodes", self.window_episodes)), 1)
+            out[k].window_episodes = max(int(stage.get("window_episodes", self.window_episodes)), 1)
+            out[k].handoff_offset, out[k].handoff_count = 0, -1
+            if buffers is not None:
+                out[k].handoff_offset, out[k].handoff_count = sum(len(b) for b in buffers[:k]), len(buffers[k])
+        return out
 
-    def _promote(self, next_stage_index: int, trigger_success_rate: float) -> None:
-        prev_stage, next_stage = self.stages[self.current_stage_index], self.stages[next_stage_index]
-        self._apply_stage(next_stage_index)
-        self.history.append({
-            "from_stage_index": self.current_stage_index, "from_stage_name": prev_stage.get("name", f"stage_{self.current_stage_index}"),
-            "to_stage_index": next_stage_index, "to_stage_name": next_stage.get("name", f"stage_{next_stage_index}"),
-            "trigger_success_rate": float(trigger_success_rate), "stage_episode_count": int(self.stage_episode_count),
-            "total_timesteps": int(self.num_timesteps)})
-        self.current_stage_index = next_stage_index
-        self.stage_episode_count = 0
-        self.recent_successes.clear()
+    # ---------------------------------------------------------------- device side
+    def attach(self, env: Any) -> None:
+        """_on_training_start: allocate the tracker next to the env; stage 0 is applied on the device before the first reset"""
+        from . import native
 
-    def on_step(self, dones: Sequence[Any], success: Sequence[Any]) -> bool:
-        """_on_step over one vectorised step (arrays in env order)."""
-        self.num_timesteps += len(dones)
-        for i, done in enumerate(dones):
-            if not done:
-                continue
-            self.stage_episode_count += 1
-            self.recent_successes.append(1 if bool(success[i]) else 0)
-            if self.current_stage_index >= len(self.stages) - 1:
-                continue
-            stage = self.stages[self.current_stage_index]
-            min_episodes = max(int(stage.get("min_episodes", self.window_episodes)), 1)
-            threshold = float(stage.get("success_rate_threshold", 1.0))
-            stage_window = max(int(stage.get("window_episodes", self.window_episodes)), 1)
-            if self.stage_episode_count < min_episodes:
-                continue
-            if len(self.recent_successes) < min(stage_window, self.window_episodes):
-                continue
-            recent = list(self.recent_successes)[-min(stage_window, len(self.recent_successes)):]
-            rate = float(sum(recent)) / float(len(recent))
-            if rate >= threshold:
-                self._promote(self.current_stage_index + 1, rate)
-        return True
+        L = env.L
+        vp, i32 = C.c_void_p, C.c_int32
+        L.kp1_dock_curriculum_create.argtypes = [vp, C.POINTER(_Stage), i32, i32, C.POINTER(vp)]
+        L.kp1_dock_curriculum_destroy.argtypes = [vp, vp]
+        L.kp1_dock_curriculum_observe.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+        L.kp1_dock_curriculum_read.argtypes = [vp, vp, C.POINTER(_State), vp]
+        self.env = env
+        buffers = self.stage_buffers(env.config)
+        if buffers is not None:
+            env.set_handoff_states([state for stage_states in buffers for state in stage_states])
+        table = self.resolved_stages(env.config, buffers)
+        with torch.cuda.device(env.device):
+            native.check(L.kp1_dock_curriculum_create(env._handle, table, len(self.stages), self.window_episodes, C.byref(self._st)))
+        env.launch_args_version = getattr(env, "launch_args_version", 0) + 1
+
+    on_training_start = attach
+
+    def observe(self, dones: torch.Tensor, steps_per_call: int) -> None:
+        self.observe_chunk(dones, int(dones.numel()), 1, 1)
+
+    def observe_chunk(self, dones_all: torch.Tensor, n_local: int, chunk_steps: int, world: int) -> None:
+        from . import native
+
+        stream = torch.cuda.current_stream(self.env.device).cuda_stream
+        native.check(self.env.L.kp1_dock_curriculum_observe(self.env._handle, self._st, C.c_void_p(dones_all.data_ptr()), int(n_local), int(chunk_steps),
+                                                            int(world), C.c_void_p(stream)))
+
+    def read(self) -> _State:
+        from . import native
+
+        out = _State()
+        stream = torch.cuda.current_stream(self.env.device).cuda_stream
+        native.check(self.env.L.kp1_dock_curriculum_read(self.env._handle, self._st, C.byref(out), C.c_void_p(stream)))
+        # the Python-side config mirror follows the stage the device applied (the C handle's mirror was updated by the call above)
+        live, c = out.stages[out.stage_index], self.env.config.c
+        for key in _STAGE_ENV_KEYS:
+            setattr(c.env, key, float(getattr(live, key)))
+        for key in _STAGE_RESET_SCALARS:
+            setattr(c.dock_reset, key, float(getattr(live, key)))
+        for key in _STAGE_RESET_VECTORS:
+            getattr(c.dock_reset, key)[:] = list(getattr(live, key)[:])
+        return out
+
+    @property
+    def current_stage_index(self) -> int:
+        return int(self.read().stage_index) if self.env is not None else 0
+
+    def _name(self, index: int) -> object:
+        return self.stages[index].get("name", f"stage_{index}")
 
     def summary(self) -> dict[str, object]:
-        rate = float(sum(self.recent_successes)) / float(len(self.recent_successes)) if self.recent_successes else 0.0
-        return {"stage_index": self.current_stage_index, "stage_name": self.stages[self.current_stage_index].get("name", f"stage_{self.current_stage_index}"),
-                "stage_episode_count": self.stage_episode_count, "recent_success_rate": rate, "history": list(self.history)}
+        st = self.read()
+        n, cap, head = int(st.ring_len), int(st.window_episodes), int(st.ring_head)
+        wins = sum(int(st.ring[(head + j) % cap]) for j in range(n))
+        events = [st.events[k] for k in range(min(int(st.n_events), MAX_HISTORY))]
+        return {"stage_index": int(st.stage_index), "stage_name": self._name(int(st.stage_index)), "stage_episode_count": int(st.stage_episode_count),
+                "recent_success_rate": float(wins) / float(n) if n else 0.0,
+                "history": [{"from_stage_index": int(e.from_stage), "from_stage_name": self._name(int(e.from_stage)), "to_stage_index": int(e.to_stage),
+                             "to_stage_name": self._name(int(e.to_stage)), "trigger_success_rate": float(e.trigger_success_rate),
+                             "stage_episode_count": int(e.stage_episode_count), "total_timesteps": int(e.total_timesteps)} for e in events]}
+
+    def close(self) -> None:
+        if self.env is not None and self._st.value:
+            self.env.L.kp1_dock_curriculum_destroy(self.env._handle, self._st)
+            self._st = C.c_void_p()
 
 
 def build_finisher_handoff_state_buffer(*, approach_policy, approach_cfg: kcfg.EnvConfig, artifact_root: str | Path | None = None, episodes: int = 500,

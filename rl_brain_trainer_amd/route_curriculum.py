@@ -1,17 +1,17 @@
 """Route prefix curriculum and the sequential route evaluator on the device engine.
 
-Mirror of kinematic_phase1/route/route_curriculum.py:17-136 (``RoutePrefixCurriculumCallback``, ``build_prefix_stages``) and
-kinematic_phase1/eval/eval_route_curriculum.py:57-248 (``_roll_one``, ``_summarize_rows``, ``_failure_reason``, ``_chunk_metrics``,
-``evaluate_sequential_route``).  The callback is a plain object fed with the vectorised env's (done, info) arrays in env order --
-what SB3 hands ``_on_step`` -- and calls ``env.set_route_window`` on promotion.  The sequential evaluator chains the final
-(q, dq, prev_action) of waypoint k into waypoint k+1, so it is serial by construction: one device env, one step per launch pair.
+What the reference does in kinematic_phase1/route/route_curriculum.py:17-136 (``RoutePrefixCurriculumCallback``: four sliding windows over
+finished episodes, promotion to the next route prefix when all four rates pass) runs here as a one-wave device tracker
+(include/kp1_route.h, kp1_route_curriculum_*) so the PPO rollout stays one hipGraph replay; this module holds its host handle.
+kinematic_phase1/eval/eval_route_curriculum.py:57-248 (sequential evaluation: the final (q, dq, prev_action) of waypoint k start
+waypoint k+1) and eval/eval_route_gate.py:17-99 (accept / reject of a checkpoint from per-prefix evaluations) keep their JSON schemas --
+status scripts read them -- with the bookkeeping done on numeric columns.
 """
 from __future__ import annotations
 
 import ctypes as C
 
 import json
-from collections import deque
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Any, Callable, Sequence
@@ -32,109 +32,6 @@ class RouteCurriculumStage:
 
 def build_prefix_stages(prefixes: Sequence[int]) -> list[RouteCurriculumStage]:
     return [RouteCurriculumStage(name=f"prefix_{int(p)}", prefix_end_index=int(p)) for p in prefixes]
-
-
-class RoutePrefixCurriculum:
-    def __init__(self, *, stages: list[RouteCurriculumStage], promotion_success_rate: float, promotion_route_ready_hit_rate: float,
-                 promotion_orientation_hit_rate: float, promotion_max_regression_rate: float, window_episodes: int, min_episodes_per_stage: int = 128) -> None:
-        if not stages:
-            raise ValueError("RoutePrefixCurriculumCallback requires at least one stage")
-        self.stages = list(stages)
-        self.promotion_success_rate = float(promotion_success_rate)
-        self.promotion_route_ready_hit_rate = float(promotion_route_ready_hit_rate)
-        self.promotion_orientation_hit_rate = float(promotion_orientation_hit_rate)
-        self.promotion_max_regression_rate = float(promotion_max_regression_rate)
-        self.window_episodes = max(int(window_episodes), 1)
-        self.min_episodes_per_stage = max(int(min_episodes_per_stage), 1)
-        self.current_stage_index = 0
-        self.stage_episode_count = 0
-        self.successes: deque[int] = deque(maxlen=self.window_episodes)
-        self.ready_hits: deque[int] = deque(maxlen=self.window_episodes)
-        self.orientation_hits: deque[int] = deque(maxlen=self.window_episodes)
-        self.regressions: deque[int] = deque(maxlen=self.window_episodes)
-        self.history: list[dict[str, object]] = []
-        self.num_timesteps = 0
-        self.training_env: Any = None
-
-    @classmethod
-    def from_config(cls, cfg: dict[str, Any], n_waypoints: int) -> "RoutePrefixCurriculum":
-        """train_route_curriculum.py:86-88, 150-160"""
-        cur = (cfg.get("route", {}) or {}).get("curriculum", {}) or {}
-        return cls(stages=build_prefix_stages(rcfg.prefix_stages(cfg, n_waypoints)), promotion_success_rate=float(cur.get("promotion_success_rate", 0.80)),
-                   promotion_route_ready_hit_rate=float(cur.get("promotion_route_ready_hit_rate", 0.80)),
-                   promotion_orientation_hit_rate=float(cur.get("promotion_orientation_hit_rate", 0.90)),
-                   promotion_max_regression_rate=float(cur.get("promotion_max_regression_rate", 0.20)),
-                   window_episodes=int(cur.get("promotion_window_episodes", 256)), min_episodes_per_stage=int(cur.get("min_episodes_per_stage", 128)))
-
-    def _apply_stage(self) -> None:
-        stage = self.stages[self.current_stage_index]
-        self.training_env.env_method("set_route_window", max_route_index=int(stage.prefix_end_index), min_route_index=1)
-
-    def on_training_start(self, env: Any) -> None:
-        self.training_env = env
-        self._apply_stage()
-
-    def _metrics(self) -> dict[str, float]:
-        def mean(xs: deque[int]) -> float:
-            return float(sum(xs)) / float(len(xs)) if xs else 0.0
-
-        return {"recent_success_rate": mean(self.successes), "recent_route_ready_hit_rate": mean(self.ready_hits),
-                "recent_orientation_hit_rate": mean(self.orientation_hits), "recent_regression_rate": mean(self.regressions)}
-
-    def _promote(self, metrics: dict[str, float]) -> None:
-        if self.current_stage_index >= len(self.stages) - 1:
-            return
-        prev = self.stages[self.current_stage_index]
-        self.current_stage_index += 1
-        nxt = self.stages[self.current_stage_index]
-        self.history.append({"from_stage": prev.name, "to_stage": nxt.name, "from_prefix_end_index": int(prev.prefix_end_index),
-                             "to_prefix_end_index": int(nxt.prefix_end_index), "total_timesteps": int(self.num_timesteps), **metrics})
-        self.stage_episode_count = 0
-        for d in (self.successes, self.ready_hits, self.orientation_hits, self.regressions):
-            d.clear()
-        self._apply_stage()
-
-    def on_step(self, dones: Sequence[Any], success: Sequence[Any], route_ready: Sequence[Any], orientation_hit: Sequence[Any],
-                regression: Sequence[Any]) -> bool:
-        """_on_step over one vectorised step (arrays in env order; ``dones`` = terminated | truncated)."""
-        self.num_timesteps += len(dones)
-        for i, done in enumerate(dones):
-            if not done:
-                continue
-            self.stage_episode_count += 1
-            self.successes.append(1 if bool(success[i]) else 0)
-            self.ready_hits.append(1 if bool(route_ready[i]) else 0)
-            self.orientation_hits.append(1 if bool(orientation_hit[i]) else 0)
-            self.regressions.append(1 if bool(regression[i]) else 0)
-            if self.stage_episode_count < self.min_episodes_per_stage or len(self.successes) < self.window_episodes:
-                continue
-            m = self._metrics()
-            if (m["recent_success_rate"] >= self.promotion_success_rate and m["recent_route_ready_hit_rate"] >= self.promotion_route_ready_hit_rate
-                    and m["recent_orientation_hit_rate"] >= self.promotion_orientation_hit_rate
-                    and m["recent_regression_rate"] <= self.promotion_max_regression_rate):
-                self._promote(m)
-        return True
-
-    def observe_env(self, env: RouteVecEnv) -> bool:
-        """on_step with the device env's last step (done bits + info arrays copied to the host)."""
-        done = env.done.cpu().numpy()
-        info = env.info()
-        return self.on_step((done & 3) != 0, (done & 4) != 0, info["route_ready"].cpu().numpy(), info["route_orientation_hit"].cpu().numpy(),
-                            info["route_regression"].cpu().numpy())
-
-    def observe_step(self, env: RouteVecEnv, done_bits: torch.Tensor) -> bool:
-        """PPO.step_callback form: ``done_bits`` = the rollout buffer row of this step (step_into does not fill env.done)."""
-        packed = torch.cat([done_bits.view(1, -1), env.episode_flags()]).cpu().numpy()     # one device->host copy per step
-        done = packed[0]
-        if not (done & 3).any():
-            self.num_timesteps += len(done)
-            return True
-        return self.on_step((done & 3) != 0, (done & 4) != 0, packed[1], packed[2], packed[3])
-
-    def summary(self) -> dict[str, object]:
-        stage = self.stages[self.current_stage_index]
-        return {"stage_index": int(self.current_stage_index), "stage_name": stage.name, "prefix_end_index": int(stage.prefix_end_index),
-                "stage_episode_count": int(self.stage_episode_count), **self._metrics(), "history": list(self.history)}
 
 
 # --------------------------------------------------------------------------------------------- the same callback on the device
@@ -173,10 +70,25 @@ class RoutePrefixCurriculumDevice:
 
     @classmethod
     def from_config(cls, cfg: dict[str, Any], n_waypoints: int) -> "RoutePrefixCurriculumDevice":
-        host = RoutePrefixCurriculum.from_config(cfg, n_waypoints)
-        return cls(stages=host.stages, promotion_success_rate=host.promotion_success_rate, promotion_route_ready_hit_rate=host.promotion_route_ready_hit_rate,
-                   promotion_orientation_hit_rate=host.promotion_orientation_hit_rate, promotion_max_regression_rate=host.promotion_max_regression_rate,
-                   window_episodes=host.window_episodes, min_episodes_per_stage=host.min_episodes_per_stage)
+        """``route.curriculum`` block of the YAML with the trainer's defaults (train_route_curriculum.py:86-88, 150-160)"""
+        block = dict((cfg.get("route", {}) or {}).get("curriculum", {}) or {})
+        defaults = {"promotion_success_rate": 0.80, "promotion_route_ready_hit_rate": 0.80, "promotion_orientation_hit_rate": 0.90,
+                    "promotion_max_regression_rate": 0.20}
+        rates = {k: float(block.get(k, v)) for k, v in defaults.items()}
+        return cls(stages=build_prefix_stages(rcfg.prefix_stages(cfg, n_waypoints)), window_episodes=int(block.get("promotion_window_episodes", 256)),
+                   min_episodes_per_stage=int(block.get("min_episodes_per_stage", 128)), **rates)
+
+    @property
+    def window_episodes(self) -> int:
+        return int(self._args[4])
+
+    @property
+    def min_episodes_per_stage(self) -> int:
+        return int(self._args[5])
+
+    @property
+    def promotion_max_regression_rate(self) -> float:
+        return float(self._args[3])
 
     def attach(self, env: RouteVecEnv) -> None:
         """_on_training_start: allocate the tracker next to the env and apply the first prefix."""
@@ -242,7 +154,7 @@ PolicyFn = Callable[[torch.Tensor], torch.Tensor]
 
 
 def _roll_one(env: RouteVecEnv, policy: PolicyFn, *, initial_q: np.ndarray, goal_index: int, initial_dq: np.ndarray, initial_prev_action: np.ndarray,
-              success_dwell_steps: int, record: list[tuple[np.ndarray, np.ndarray]] | None = None) -> dict[str, Any]:
+              success_dwell_steps: int) -> dict[str, Any]:
     obs = env.reset(options={"route_index": int(goal_index), "start_route_index": 0, "initial_q": initial_q[None], "initial_dq": initial_dq[None],
                              "initial_prev_action": initial_prev_action[None], "evaluator_state": True})
     info = env.info()
@@ -255,8 +167,6 @@ def _roll_one(env: RouteVecEnv, policy: PolicyFn, *, initial_q: np.ndarray, goal
     done = 0
     while not (done & 3):
         action = policy(obs)
-        if record is not None:   # the observation the action was computed from (collect_route_teacher_rollout.py:68-73)
-            record.append((obs[0, :env.obs_dim].cpu().numpy().astype(np.float32), action[0].detach().cpu().numpy().astype(np.float32)))
         obs, _, d = env.step(action, auto_reset=False)
         done = int(d[0])
         steps += 1
@@ -279,60 +189,63 @@ def _roll_one(env: RouteVecEnv, policy: PolicyFn, *, initial_q: np.ndarray, goal
     }
 
 
+# first matching rule names why a waypoint failed (eval_route_curriculum.py:113-124): (label, row key, limit); a value above its limit matches
+_FAILURE_RULES = (("position", "final_position_error", 0.010), ("orientation", "final_orientation_error", 0.150),
+                  ("motion_action", "final_action_magnitude", 1.20), ("motion_action", "final_dq_norm", 0.040), ("q_error", "final_q_error", 0.500))
+_ROUTE_CHUNKS = np.array([1, 41, 81, 121, 181, 261, 361, 484])       # chunk c covers route indices [_ROUTE_CHUNKS[c], _ROUTE_CHUNKS[c + 1])
+_ROW_MEANS = ("final_position_error", "final_orientation_error", "final_q_error")
+
+
 def _failure_reason(row: dict[str, Any]) -> str:
-    if row["final_position_error"] > 0.010:
-        return "position"
-    if row["final_orientation_error"] > 0.150:
-        return "orientation"
-    if row.get("final_action_magnitude", 0.0) > 1.20 or row.get("final_dq_norm", 0.0) > 0.040:
-        return "motion_action"
-    if row["final_q_error"] > 0.500:
-        return "q_error"
-    if not row["route_ready_dwell"]:
-        return "dwell_or_motion"
-    return "unknown"
+    for label, key, limit in _FAILURE_RULES:
+        if float(row.get(key, 0.0)) > limit:
+            return label
+    return "unknown" if row["route_ready_dwell"] else "dwell_or_motion"
+
+
+def _row_columns(rows: list[dict[str, Any]]) -> dict[str, np.ndarray]:
+    """the per-waypoint rows of a sequential evaluation as columns"""
+    flags = {k: np.fromiter((bool(r[k]) for r in rows), dtype=bool, count=len(rows)) for k in ("success", "route_ready_hit", "route_ready_dwell")}
+    reals = {k: np.fromiter((float(r[k]) for r in rows), dtype=np.float64, count=len(rows)) for k in _ROW_MEANS}
+    return {**flags, **reals, "route_index": np.fromiter((int(r["route_index"]) for r in rows), dtype=np.int64, count=len(rows))}
 
 
 def summarize_rows(rows: list[dict[str, Any]], route_progress_m: np.ndarray) -> dict[str, Any]:
+    """route_eval_sequential_summary.json: rates over all targets, the unbroken success prefix from the start and the route length it covers,
+    the first failed waypoint and why, mean / max final errors"""
     if not rows:
         return {"target_count": 0}
-    first_failure = next((row for row in rows if not row["success"]), None)
-    longest_prefix = 0
-    for row in rows:
-        if row["success"]:
-            longest_prefix += 1
-        else:
-            break
-    prefix_end = min(longest_prefix, len(route_progress_m) - 1)
-    return {
-        "target_count": len(rows), "success_rate": float(np.mean([row["success"] for row in rows])),
-        "route_ready_hit_rate": float(np.mean([row["route_ready_hit"] for row in rows])),
-        "route_ready_dwell_rate": float(np.mean([row["route_ready_dwell"] for row in rows])), "longest_success_prefix": int(longest_prefix),
-        "cumulative_successful_route_distance_m": float(route_progress_m[prefix_end] - route_progress_m[0]),
-        "first_failure_index": None if first_failure is None else int(first_failure["route_index"]),
-        "first_failure_reason": None if first_failure is None else _failure_reason(first_failure),
-        "mean_final_position_error": float(np.mean([row["final_position_error"] for row in rows])),
-        "mean_final_orientation_error": float(np.mean([row["final_orientation_error"] for row in rows])),
-        "mean_final_q_error": float(np.mean([row["final_q_error"] for row in rows])),
-        "max_final_position_error": float(np.max([row["final_position_error"] for row in rows])),
-        "max_final_orientation_error": float(np.max([row["final_orientation_error"] for row in rows])),
-    }
+    col = _row_columns(rows)
+    failed = np.flatnonzero(~col["success"])
+    prefix = int(failed[0]) if failed.size else len(rows)
+    reached = min(prefix, len(route_progress_m) - 1)
+    out: dict[str, Any] = {"target_count": len(rows)}
+    out.update({name: float(col[key].mean()) for name, key in (("success_rate", "success"), ("route_ready_hit_rate", "route_ready_hit"),
+                                                               ("route_ready_dwell_rate", "route_ready_dwell"))})
+    out["longest_success_prefix"] = prefix
+    out["cumulative_successful_route_distance_m"] = float(route_progress_m[reached] - route_progress_m[0])
+    out["first_failure_index"] = int(col["route_index"][failed[0]]) if failed.size else None
+    out["first_failure_reason"] = _failure_reason(rows[int(failed[0])]) if failed.size else None
+    out.update({f"mean_{k}": float(col[k].mean()) for k in _ROW_MEANS})
+    out.update({f"max_{k}": float(col[k].max()) for k in _ROW_MEANS[:2]})
+    return out
 
 
 def chunk_metrics(rows: list[dict[str, Any]]) -> dict[str, Any]:
-    chunks = [(1, 40), (41, 80), (81, 120), (121, 180), (181, 260), (261, 360), (361, 483)]
+    """route_chunk_metrics.json: the same rates per fixed stretch of the route (chunks without a target are left out)"""
+    if not rows:
+        return {}
+    col = _row_columns(rows)
+    which = np.digitize(col["route_index"], _ROUTE_CHUNKS) - 1
     out: dict[str, Any] = {}
-    for idx, (lo, hi) in enumerate(chunks):
-        subset = [row for row in rows if lo <= row["route_index"] <= hi]
-        if not subset:
+    for c in range(len(_ROUTE_CHUNKS) - 1):
+        sel = which == c
+        if not sel.any():
             continue
-        out[f"chunk_{idx}_{lo}_{hi}"] = {
-            "target_count": len(subset), "success_rate": float(np.mean([row["success"] for row in subset])),
-            "route_ready_hit_rate": float(np.mean([row["route_ready_hit"] for row in subset])),
-            "mean_final_position_error": float(np.mean([row["final_position_error"] for row in subset])),
-            "mean_final_orientation_error": float(np.mean([row["final_orientation_error"] for row in subset])),
-            "mean_final_q_error": float(np.mean([row["final_q_error"] for row in subset])),
-        }
+        entry: dict[str, Any] = {"target_count": int(sel.sum()), "success_rate": float(col["success"][sel].mean()),
+                                 "route_ready_hit_rate": float(col["route_ready_hit"][sel].mean())}
+        entry.update({f"mean_{k}": float(col[k][sel].mean()) for k in _ROW_MEANS})
+        out[f"chunk_{c}_{int(_ROUTE_CHUNKS[c])}_{int(_ROUTE_CHUNKS[c + 1]) - 1}"] = entry
     return out
 
 
@@ -376,96 +289,37 @@ def evaluate_sequential_route(*, policy: PolicyFn | Callable[[RouteVecEnv], Poli
 
 
 # --------------------------------------------------------------------------------------------- sequential gate
-def _passes_prefix120(summary: dict[str, Any], *, min_success_rate: float) -> bool:
-    return int(summary.get("longest_success_prefix", 0)) >= 120 and float(summary.get("success_rate", 0.0)) >= min_success_rate
-
-
 def evaluate_route_gate(*, evaluate: Callable[..., dict[str, Any]], artifact_root: str | Path, prefixes: Sequence[int], full_end_index: int | None,
                         min_prefix120_success_rate: float, best_full_longest_prefix: int, full_prefix_tolerance: int, checkpoint: str = "",
                         config: str = "", route_path: str = "") -> dict[str, Any]:
-    """eval/eval_route_gate.py:17-99.  ``evaluate(artifact_root=, start_index=, end_index=)`` runs one sequential evaluation (the trainer
-    binds evaluate_sequential_route to the policy under test); the accept / reject rules and the summary file are the reference's."""
+    """Accept or reject a checkpoint from sequential evaluations at several prefixes (eval/eval_route_gate.py:17-99; summary schema
+    v5.route_gate.v1).  ``evaluate(artifact_root=, start_index=, end_index=)`` runs one sequential evaluation -- the trainer binds
+    evaluate_sequential_route to the policy under test.  A checkpoint passes when it (1) still chains all of prefix 120 at the required
+    success rate, (2) gets beyond waypoint 120 on prefix 180, (3) has its first prefix-180 failure after 120, and (4) on the full route
+    stays within the tolerance of the best chain length seen so far."""
     root = Path(artifact_root)
     root.mkdir(parents=True, exist_ok=True)
-    prefix_results: dict[str, Any] = {}
-    for prefix in prefixes:
-        prefix_results[f"prefix_{prefix}"] = evaluate(artifact_root=root / f"prefix_{prefix}", start_index=1, end_index=int(prefix))
-    full_summary = None
-    if full_end_index is not None:
-        full_summary = evaluate(artifact_root=root / f"full_{full_end_index}", start_index=1, end_index=int(full_end_index))
-    p120 = prefix_results.get("prefix_120")
-    p180 = prefix_results.get("prefix_180")
-    prefix120_retained = bool(p120 and _passes_prefix120(p120, min_success_rate=min_prefix120_success_rate))
-    expands_beyond_120 = bool(p180 and int(p180.get("longest_success_prefix", 0)) > 120)
-    first_failure_not_before_120 = bool(p180 and (p180.get("first_failure_index") is None or int(p180.get("first_failure_index", 0)) > 120))
-    full_not_too_regressed = True
-    if full_summary is not None:
-        full_not_too_regressed = int(full_summary.get("longest_success_prefix", 0)) >= int(best_full_longest_prefix - full_prefix_tolerance)
-    accepted = bool(prefix120_retained and expands_beyond_120 and first_failure_not_before_120 and full_not_too_regressed)
-    reasons: list[str] = []
-    if not prefix120_retained:
-        reasons.append("prefix120_retention_failed")
-    if not expands_beyond_120:
-        reasons.append("prefix180_did_not_expand_beyond_120")
-    if not first_failure_not_before_120:
-        reasons.append("prefix180_failed_before_or_at_120")
-    if not full_not_too_regressed:
-        reasons.append("full_route_prefix_regressed_too_much")
+    runs = {f"prefix_{int(p)}": evaluate(artifact_root=root / f"prefix_{int(p)}", start_index=1, end_index=int(p)) for p in prefixes}
+    full = None if full_end_index is None else evaluate(artifact_root=root / f"full_{full_end_index}", start_index=1, end_index=int(full_end_index))
+
+    def chain(summary: dict[str, Any] | None) -> int:
+        return int(summary.get("longest_success_prefix", 0)) if summary else 0
+
+    at120, at180 = runs.get("prefix_120"), runs.get("prefix_180")
+    first_fail_180 = at180.get("first_failure_index") if at180 else 0
+    checks = (
+        ("prefix120_retention_failed", bool(at120) and chain(at120) >= 120 and float(at120.get("success_rate", 0.0)) >= min_prefix120_success_rate),
+        ("prefix180_did_not_expand_beyond_120", bool(at180) and chain(at180) > 120),
+        ("prefix180_failed_before_or_at_120", bool(at180) and (first_fail_180 is None or int(first_fail_180) > 120)),
+        ("full_route_prefix_regressed_too_much", full is None or chain(full) >= int(best_full_longest_prefix - full_prefix_tolerance)),
+    )
+    rejected = [reason for reason, ok in checks if not ok]
     summary = {
-        "schema_version": "v5.route_gate.v1", "checkpoint": str(checkpoint), "config": str(config), "route_path": str(route_path), "accepted": accepted,
-        "rejection_reasons": reasons,
+        "schema_version": "v5.route_gate.v1", "checkpoint": str(checkpoint), "config": str(config), "route_path": str(route_path),
+        "accepted": not rejected, "rejection_reasons": rejected,
         "criteria": {"min_prefix120_success_rate": float(min_prefix120_success_rate), "best_full_longest_prefix": int(best_full_longest_prefix),
                      "full_prefix_tolerance": int(full_prefix_tolerance)},
-        "prefix_results": prefix_results, "full_result": full_summary,
+        "prefix_results": runs, "full_result": full,
     }
     (root / "route_gate_summary.json").write_text(json.dumps(summary, indent=2))
-    return summary
-
-
-# --------------------------------------------------------------------------------------------- teacher-anchor dataset
-def collect_teacher_rollout(*, policy: PolicyFn, cfg: dict[str, Any], route_q: np.ndarray, artifact_root: str | Path, start_index: int = 1, end_index: int = 120,
-                            device: int = 0, checkpoint: str = "", config: str = "", route_path: str = "") -> dict[str, Any]:
-    """route/collect_route_teacher_rollout.py:22-123: the sequential evaluator's chained episodes with every (observation, action) pair
-    recorded; the walk stops at the first failed waypoint and that episode's samples are dropped.  Writes
-    ``teacher_route_anchor_dataset.npz`` (``obs__<key>``, ``actions``, ``route_index``, ``step``) + the summary JSON."""
-    W = int(route_q.shape[0])
-    seq_off = {**cfg, "route": {**(cfg.get("route", {}) or {}), "sequence": {**((cfg.get("route", {}) or {}).get("sequence", {}) or {}), "enabled": False}}}
-    base = kcfg.to_env_config(cfg)
-    env = RouteVecEnv(base, rcfg.route_config_from_dict(seq_off, max_route_index=end_index), route_q, 1, device=device, seed=0)
-    layout = rcfg.ROUTE_OBS_LAYOUT if env.obs_dim == rcfg.ROUTE_OBS_DIM else kcfg.OBS_LAYOUT
-    obs_rows: list[np.ndarray] = []
-    action_rows: list[np.ndarray] = []
-    meta: list[tuple[int, int]] = []
-    ok: list[int] = []
-    failed: list[int] = []
-    cq = np.asarray(route_q[max(start_index - 1, 0)], dtype=float).copy()
-    cdq, cpa = np.zeros_like(cq), np.zeros_like(cq)
-    dwell = int(base.c.termination.success_dwell_steps)
-    for idx in range(int(start_index), min(int(end_index), W - 1) + 1):
-        rec: list[tuple[np.ndarray, np.ndarray]] = []
-        row = _roll_one(env, policy, initial_q=cq, goal_index=idx, initial_dq=cdq, initial_prev_action=cpa, success_dwell_steps=dwell, record=rec)
-        cq, cdq, cpa = row["final_q"], row["final_dq"], row["final_prev_action"]
-        if not row["success"]:
-            failed.append(idx)
-            break
-        ok.append(idx)
-        for step, (o, a) in enumerate(rec):
-            obs_rows.append(o)
-            action_rows.append(a)
-            meta.append((idx, step))
-    env.close()
-    root = Path(artifact_root)
-    root.mkdir(parents=True, exist_ok=True)
-    dataset_path = root / "teacher_route_anchor_dataset.npz"
-    obs_mat = np.asarray(obs_rows, dtype=np.float32).reshape(len(obs_rows), sum(w for _, w in layout.values()))
-    arrays: dict[str, np.ndarray] = {"actions": np.asarray(action_rows, dtype=np.float32).reshape(len(action_rows), kcfg.NJ),
-                                     "route_index": np.asarray([m[0] for m in meta], dtype=np.int32), "step": np.asarray([m[1] for m in meta], dtype=np.int32)}
-    for key, (off, width) in layout.items():
-        arrays[f"obs__{key}"] = obs_mat[:, off:off + width]
-    np.savez_compressed(dataset_path, **arrays)
-    summary = {"schema_version": "v5.route_teacher_anchor_dataset.v1", "checkpoint": str(checkpoint), "config": str(config), "route_path": str(route_path),
-               "dataset_path": str(dataset_path), "start_index": int(start_index), "requested_end_index": int(end_index), "successful_indices": ok,
-               "failed_indices": failed, "sample_count": int(len(action_rows)), "obs_keys": sorted(layout.keys()),
-               "action_dim": int(kcfg.NJ) if action_rows else 0}
-    (root / "teacher_route_anchor_summary.json").write_text(json.dumps(summary, indent=2))
     return summary

@@ -2,7 +2,7 @@
 
 Mirror of kinematic_phase1/training/train_dock_policy.py:39-131 (same YAML chain dock_default <- ppo_default <- overlay, same CLI
 flags, same artefact names) on the device engine, plus the dock reverse curriculum the reference wires into its TD3 dock trainer
-(train_dock_td3_policy.py:121-129: ``training.dock_reverse_curriculum``), driven here by the PPO loop's per-step hook.
+(train_dock_td3_policy.py:121-129: ``training.dock_reverse_curriculum``), running here as a device tracker inside the rollout graph.
 
     python -m rl_brain_trainer_amd.train_dock --config rl_brain_trainer_amd/configs/dock_workspace_handoff_noop_ft_12env.yaml \
         --run-id finisher --artifact-root /tmp/finisher --total-timesteps 2000000 --n-envs 4096
@@ -87,25 +87,18 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
     batch = args.batch_size or max(n_envs * args.n_steps * world // 64, 64)
     model_kwargs = {k: v for k, v in algo.items() if k not in ("total_timesteps", "n_steps", "batch_size")}
     pcfg = PPOConfig.from_algo_kwargs(model_kwargs, n_steps=args.n_steps, batch_size=batch, hidden=args.hidden)
-    ppo = PPO(env, pcfg, dist=Dist(), backend="hip" if args.hidden in (128, 256) else "torch")
+    # training.dock_reverse_curriculum (train_dock_td3_policy.py:121-129): a device tracker after every env step, inside the rollout hipGraph
+    curriculum = None
+    cur_cfg = runtime.get("dock_reverse_curriculum", {}) or {}
+    if bool(cur_cfg.get("enabled", False)):
+        curriculum = DockReverseCurriculum(stages=list(cur_cfg.get("stages", [])), window_episodes=int(cur_cfg.get("window_episodes", 100)),
+                                           handoff_base_dirs=base_dirs)
+    ppo = PPO(env, pcfg, curriculum=curriculum, dist=Dist(), backend="hip" if args.hidden in (128, 256) else "torch")
     if args.resume_from and Path(args.resume_from).exists():
         # PPO.load(resume, env=vec_env) + learn(reset_num_timesteps=False) (train_dock_policy.py:89-102)
         ppo.load_checkpoint(args.resume_from, restore_timesteps=True, restore_hyperparameters=True)
         if rank == 0:
             print(f"Resuming dock policy from {args.resume_from}")
-
-    curriculum = None
-    cur_cfg = runtime.get("dock_reverse_curriculum", {}) or {}
-    if bool(cur_cfg.get("enabled", False)):
-        curriculum = DockReverseCurriculum(stages=list(cur_cfg.get("stages", [])), window_episodes=int(cur_cfg.get("window_episodes", 100)))
-        curriculum.on_training_start(env)
-
-        def on_step(done_dev: torch.Tensor) -> None:
-            # the callback scans (done, info["success"]) in env order; data parallel: every rank sees all ranks' envs in global order
-            d = ppo.dist.all_gather_bytes(done_dev).cpu().numpy()
-            curriculum.on_step((d & 3) != 0, (d & 4) != 0)
-
-        ppo.step_callback = on_step
 
     total = int(algo.get("total_timesteps", 100_000))
     t0 = time.time()

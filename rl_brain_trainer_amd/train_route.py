@@ -3,8 +3,8 @@
 Mirror of ``kinematic_phase1/train_route_curriculum.py:69-199``: same YAML chain (approach_default <- ppo_default <- overlay), same
 CLI flags, same artefacts (``model_latest.zip``, ``curriculum_history.json``, ``route_eval_sequential/``, ``route_gate/``,
 ``model_sequential_gate_accepted.zip``, ``training_summary.json``), with the reference's three callbacks mapped onto the device
-engine: periodic checkpoints, the prefix curriculum (``RoutePrefixCurriculum`` fed from the PPO loop's per-step hook) and the
-teacher-anchor imitation step between rollout and update (``RouteTeacherAnchor``).  The envs are ``RouteVecEnv`` lanes (single or
+engine: periodic checkpoints, the prefix curriculum (``RoutePrefixCurriculumDevice``: a one-wave tracker after every env step, inside the
+rollout hipGraph) and the teacher-anchor imitation step between rollout and update (``RouteTeacherAnchor``).  The envs are ``RouteVecEnv`` lanes (single or
 sequence wrapper, 56- or 80-float observation as the YAML says); the PPO update runs on the MFMA kernels.
 
     python -m rl_brain_trainer_amd.train_route --config <route yaml> --route-path <route_q_dense.json> --run-id route \
@@ -25,7 +25,7 @@ from . import checkpoint
 from . import config as kcfg
 from . import route_config as rcfg
 from .ppo import PPO, Dist, PPOConfig
-from .route_curriculum import RoutePrefixCurriculum, RoutePrefixCurriculumDevice, evaluate_route_gate, evaluate_sequential_route
+from .route_curriculum import RoutePrefixCurriculumDevice, evaluate_route_gate, evaluate_sequential_route
 from .route_env import RouteVecEnv
 from .teacher_anchor import RouteTeacherAnchor, TeacherAnchorConfig
 
@@ -53,7 +53,6 @@ def build_arg_parser() -> argparse.ArgumentParser:
     p.add_argument("--hidden", type=int, default=256)
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--log-every", type=int, default=0)
-    p.add_argument("--host-curriculum", action="store_true", help="run the prefix curriculum as a host callback per step (eager rollout) instead of on the device")
     return p
 
 
@@ -86,19 +85,15 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
     n_steps = int(args.n_steps or algo.get("n_steps", 2048))
     batch = int(args.batch_size or algo.get("batch_size", 64))
     pcfg = PPOConfig.from_algo_kwargs(model_kwargs, n_steps=n_steps, batch_size=batch, hidden=args.hidden)
-    # the prefix curriculum: a device tracker after every env step (the rollout stays one hipGraph replay), or the host callback
+    # the prefix curriculum: a device tracker after every env step (the rollout stays one hipGraph replay)
     hip = args.hidden in (128, 256)
-    curriculum = (RoutePrefixCurriculum if (args.host_curriculum or not hip) else RoutePrefixCurriculumDevice).from_config(cfg, W)
-    on_device = isinstance(curriculum, RoutePrefixCurriculumDevice)
-    ppo = PPO(env, pcfg, curriculum=curriculum if on_device else None, dist=Dist(), backend="hip" if hip else "torch")
+    curriculum = RoutePrefixCurriculumDevice.from_config(cfg, W)
+    ppo = PPO(env, pcfg, curriculum=curriculum, dist=Dist(), backend="hip" if hip else "torch")
     if init_checkpoint:
         # PPO.load(..., env=vec_env) + learn(reset_num_timesteps=False): weights, Adam state, step clock; the YAML's learning rate wins
         ppo.load_checkpoint(init_checkpoint, restore_timesteps=True, restore_hyperparameters=True)
         print(f"Resuming route policy from {init_checkpoint}")
 
-    if not on_device:
-        curriculum.on_training_start(env)
-        ppo.step_callback = lambda done_bits: curriculum.observe_step(env, done_bits)
     anchor = None
     anchor_cfg = TeacherAnchorConfig(**(route_cfg.get("teacher_anchor", {}) or {}))
     if anchor_cfg.enabled:

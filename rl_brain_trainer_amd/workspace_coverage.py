@@ -224,77 +224,114 @@ def generate_workspace_start_state_map(env_cfg: kcfg.EnvConfig, *, seed: int, st
 
 
 # --------------------------------------------------------------------------------------------- pairs
+# Difficulty classes of a (start, target) pair for the layered pair curriculum (workspace/start_target_pair_sampler.py:13-50).  The rule set
+# is evaluated for ALL pairs at once on columns; the first rule that holds gives the class:
+#   retention  start is the home pose or the end of a successful rollout, and the target belongs to a stage <= 7
+#   local      joint distance <= 0.28
+#   frontier / stress   by the target's previous eval success rate when one is known: [0.35, 0.80] / below 0.35
+#   medium     joint distance <= 0.70
+#   frontier if the target stage is <= 10, else stress
 LOCAL_Q_L2, MEDIUM_Q_L2, FRONTIER_SUCCESS_LOW, FRONTIER_SUCCESS_HIGH = 0.28, 0.70, 0.35, 0.80
+_RETENTION_SOURCES = ("home", "successful_rollout")
+
+
+def _classify_columns(*, start_source: np.ndarray, stage_id: np.ndarray, stage_known: np.ndarray, prev_success: np.ndarray, q_l2: np.ndarray) -> np.ndarray:
+    """stage_id: int column (0 where unknown, stage_known says which); prev_success: float column, NaN where the target has no eval history"""
+    has_rate = ~np.isnan(prev_success)
+    rate = np.where(has_rate, prev_success, 1.0)
+    rules = [
+        (np.isin(start_source, _RETENTION_SOURCES) & stage_known & (stage_id <= 7), "retention"),
+        (q_l2 <= LOCAL_Q_L2, "local"),
+        (has_rate & (rate >= FRONTIER_SUCCESS_LOW) & (rate <= FRONTIER_SUCCESS_HIGH), "frontier"),
+        (has_rate & (rate < FRONTIER_SUCCESS_LOW), "stress"),
+        (q_l2 <= MEDIUM_Q_L2, "medium"),
+        (stage_id <= 10, "frontier"),
+    ]
+    return np.select([m for m, _ in rules], [c for _, c in rules], default="stress")
+
+
+def _stage_columns(stage_values: Sequence[Any]) -> tuple[np.ndarray, np.ndarray]:
+    known = np.fromiter((v is not None for v in stage_values), dtype=bool, count=len(stage_values))
+    ids = np.fromiter((int(v) if v is not None else 0 for v in stage_values), dtype=np.int64, count=len(stage_values))
+    return ids, known
 
 
 def classify_pair(*, start: dict[str, Any], target: dict[str, Any], q_l2: float) -> str:
-    target_success = target.get("previous_eval_success_rate")
-    if start.get("source_type") in {"home", "successful_rollout"} and target.get("stage_id") is not None and int(target["stage_id"]) <= 7:
-        return "retention"
-    if q_l2 <= LOCAL_Q_L2:
-        return "local"
-    if target_success is not None:
-        success = float(target_success)
-        if FRONTIER_SUCCESS_LOW <= success <= FRONTIER_SUCCESS_HIGH:
-            return "frontier"
-        if success < FRONTIER_SUCCESS_LOW:
-            return "stress"
-    if q_l2 <= MEDIUM_Q_L2:
-        return "medium"
-    return "frontier" if int(target.get("stage_id") or 0) <= 10 else "stress"
+    ids, known = _stage_columns([target.get("stage_id")])
+    prev = target.get("previous_eval_success_rate")
+    return str(_classify_columns(start_source=np.array([start.get("source_type")], dtype=object), stage_id=ids, stage_known=known,
+                                 prev_success=np.array([np.nan if prev is None else float(prev)]), q_l2=np.array([float(q_l2)]))[0])
+
+
+def _table(items: list[dict[str, Any]], key: str, width: int) -> np.ndarray:
+    return np.asarray([it[key] for it in items], dtype=np.float64).reshape(len(items), width)
 
 
 def build_pair_sampler_summary(*, starts: list[dict[str, Any]], targets: list[dict[str, Any]], seed: int, pair_count: int
                                ) -> tuple[list[dict[str, Any]], dict[str, Any]]:
-    rng = np.random.default_rng(seed)
+    """start_target_pair_sampler.py:53-115.  The (start, target) picks are two scalar ``rng.integers`` draws per pair in the reference's order
+    (that order IS the sampler); distances, margins and difficulty classes are then computed for all pairs at once."""
     if not starts or not targets:
         return [], {"pair_count": 0, "reason": "empty start or target map"}
-    pairs: list[dict[str, Any]] = []
-    for idx in range(max(pair_count, 0)):
-        start = starts[int(rng.integers(0, len(starts)))]
-        target = targets[int(rng.integers(0, len(targets)))]
-        q_l2 = float(np.linalg.norm(np.asarray(target["q_target"], dtype=float) - np.asarray(start["q_start"], dtype=float)))
-        start_pos, target_pos = np.asarray(start["ee_position"], dtype=float), np.asarray(target["ee_target_position"], dtype=float)
-        pairs.append({
-            "pair_id": f"pair_{idx:06d}", "start_id": start["start_id"], "target_id": target["target_id"],
-            "start_source_type": start.get("source_type"), "target_source_type": target.get("source_type"), "target_stage_id": target.get("stage_id"),
-            "start_bucket_id": start.get("bucket_id"), "target_bucket_id": target.get("bucket_id"), "joint_distance_l2": q_l2,
-            "ee_position_distance": float(np.linalg.norm(target_pos - start_pos)),
-            "orientation_distance": float(np.linalg.norm(np.asarray(target["ee_target_orientation"], dtype=float) - np.asarray(start["ee_orientation"], dtype=float))),
-            "z_displacement": float(abs(target_pos[2] - start_pos[2])),
-            "start_joint_limit_margin": float(start.get("joint_limit_margin_min", 0.0)),
-            "target_joint_limit_margin": float(target.get("joint_limit_margin_min", 0.0)),
-            "difficulty_class": classify_pair(start=start, target=target, q_l2=q_l2),
-        })
-    class_counts: dict[str, int] = {}
-    for p in pairs:
-        class_counts[str(p["difficulty_class"])] = class_counts.get(str(p["difficulty_class"]), 0) + 1
+    rng = np.random.default_rng(seed)
+    P = max(int(pair_count), 0)
+    picks = np.array([(int(rng.integers(0, len(starts))), int(rng.integers(0, len(targets)))) for _ in range(P)], dtype=np.int64).reshape(P, 2)
+    si, ti = picks[:, 0], picks[:, 1]
+    start_pos, target_pos = _table(starts, "ee_position", 3)[si], _table(targets, "ee_target_position", 3)[ti]
+    q_l2 = np.linalg.norm(_table(targets, "q_target", 7)[ti] - _table(starts, "q_start", 7)[si], axis=1)
+    ee_dist = np.linalg.norm(target_pos - start_pos, axis=1)
+    ori_dist = np.linalg.norm(_table(targets, "ee_target_orientation", 3)[ti] - _table(starts, "ee_orientation", 3)[si], axis=1)
+    z_disp = np.abs(target_pos[:, 2] - start_pos[:, 2])
+    stage_all, known_all = _stage_columns([t.get("stage_id") for t in targets])
+    prev_all = np.array([np.nan if t.get("previous_eval_success_rate") is None else float(t["previous_eval_success_rate"]) for t in targets])
+    source_all = np.array([s_.get("source_type") for s_ in starts], dtype=object)
+    classes = _classify_columns(start_source=source_all[si], stage_id=stage_all[ti], stage_known=known_all[ti], prev_success=prev_all[ti], q_l2=q_l2)
+    margin_s = np.array([float(s_.get("joint_limit_margin_min", 0.0)) for s_ in starts])[si]
+    margin_t = np.array([float(t.get("joint_limit_margin_min", 0.0)) for t in targets])[ti]
+    pairs = []
+    for k in range(P):
+        st, tg = starts[int(si[k])], targets[int(ti[k])]
+        pairs.append({"pair_id": f"pair_{k:06d}", "start_id": st["start_id"], "target_id": tg["target_id"], "start_source_type": st.get("source_type"),
+                      "target_source_type": tg.get("source_type"), "target_stage_id": tg.get("stage_id"), "start_bucket_id": st.get("bucket_id"),
+                      "target_bucket_id": tg.get("bucket_id"), "joint_distance_l2": float(q_l2[k]), "ee_position_distance": float(ee_dist[k]),
+                      "orientation_distance": float(ori_dist[k]), "z_displacement": float(z_disp[k]), "start_joint_limit_margin": float(margin_s[k]),
+                      "target_joint_limit_margin": float(margin_t[k]), "difficulty_class": str(classes[k])})
+    names, first, counts = np.unique(classes, return_index=True, return_counts=True) if P else (np.array([]), np.array([]), np.array([]))
+    order = np.argsort(first)
     summary = {
-        "seed": int(seed), "pair_count": len(pairs), "start_count": len(starts), "target_count": len(targets), "difficulty_class_counts": class_counts,
-        "mean_joint_distance_l2": float(np.mean([p["joint_distance_l2"] for p in pairs])) if pairs else 0.0,
-        "mean_ee_position_distance": float(np.mean([p["ee_position_distance"] for p in pairs])) if pairs else 0.0,
-        "max_joint_distance_l2": float(max((p["joint_distance_l2"] for p in pairs), default=0.0)),
+        "seed": int(seed), "pair_count": P, "start_count": len(starts), "target_count": len(targets),
+        "difficulty_class_counts": {str(names[j]): int(counts[j]) for j in order},
+        "mean_joint_distance_l2": float(q_l2.mean()) if P else 0.0, "mean_ee_position_distance": float(ee_dist.mean()) if P else 0.0,
+        "max_joint_distance_l2": float(q_l2.max()) if P else 0.0,
         "pair_curriculum_note": "Pairs are classified for layered curriculum; full-random stress pairs should remain a minority during training.",
     }
     return pairs, summary
 
 
+_SPLIT_RULES = {   # eval split -> (lowest target stage, highest target stage, admitted difficulty classes); eval_full_workspace_coverage.py:58-72
+    "known": (None, 8, ("retention", "local", "medium")),
+    "frontier": (8, 11, ("medium", "frontier", "stress")),
+}
+
+
 def select_pairs(pairs: list[dict[str, Any]], *, mode: str, limit: int, rng: np.random.Generator) -> list[dict[str, Any]]:
-    """eval_full_workspace_coverage.py:58-72"""
-    if mode == "known":
-        pool = [p for p in pairs if int(p.get("target_stage_id") or 0) <= 8 and p.get("difficulty_class") in {"retention", "local", "medium"}]
-    elif mode == "frontier":
-        pool = [p for p in pairs if 8 <= int(p.get("target_stage_id") or 0) <= 11 and p.get("difficulty_class") in {"medium", "frontier", "stress"}]
-    elif mode == "stress":
-        pool = pairs
+    """the pairs an eval split runs: a stage / class filter (the whole list for the stress split, or when the filter leaves nothing), cut to
+    ``limit`` by ONE ``rng.choice`` without replacement"""
+    if mode == "stress":
+        keep = np.ones(len(pairs), dtype=bool)
+    elif mode in _SPLIT_RULES:
+        lo, hi, classes = _SPLIT_RULES[mode]
+        stage, _ = _stage_columns([p.get("target_stage_id") for p in pairs])
+        cls = np.array([p.get("difficulty_class") for p in pairs], dtype=object)
+        keep = (stage <= hi) & np.isin(cls, classes)
+        if lo is not None:
+            keep &= stage >= lo
     else:
         raise ValueError(f"Unknown pair eval mode: {mode}")
-    if not pool:
-        pool = pairs
-    if len(pool) <= limit:
-        return list(pool)
-    indices = rng.choice(len(pool), size=limit, replace=False)
-    return [pool[int(i)] for i in indices]
+    pool = np.flatnonzero(keep) if keep.any() else np.arange(len(pairs))
+    if pool.size > limit:
+        pool = pool[rng.choice(pool.size, size=limit, replace=False)]
+    return [pairs[int(i)] for i in pool]
 
 
 # --------------------------------------------------------------------------------------------- bucket priorities
@@ -334,36 +371,44 @@ def update_bucket_priorities(bucket_metrics: dict[str, dict[str, Any]]) -> list[
 
 
 # --------------------------------------------------------------------------------------------- summaries
-def _mean(values: Sequence[float | bool]) -> float:
-    return float(np.mean(values)) if len(values) else 0.0
+_SUMMARY_MEANS = (("success_rate", "success"), ("ready_rate", "finisher_ready_hit"), ("dwell_success_rate", "finisher_ready_dwell"),
+                  ("mean_final_position_error", "final_position_error"), ("mean_final_orientation_error", "final_orientation_error"),
+                  ("mean_final_action_magnitude", "final_action_magnitude"), ("mean_final_dq_norm", "final_dq_norm"),
+                  ("average_start_target_joint_distance", "joint_distance_l2"), ("average_start_target_ee_distance", "ee_position_distance"))
+
+
+def _column(rows: list[dict[str, Any]], key: str) -> np.ndarray:
+    return np.fromiter((float(r[key]) for r in rows), dtype=np.float64, count=len(rows))
+
+
+def _groups(labels: list[str]) -> list[tuple[str, np.ndarray]]:
+    """(label, row indices) per distinct label, in order of first appearance"""
+    arr = np.array(labels, dtype=object)
+    names, first, inverse = np.unique(arr, return_index=True, return_inverse=True) if len(labels) else (np.array([]), np.array([]), np.array([]))
+    return [(str(names[j]), np.flatnonzero(inverse == j)) for j in np.argsort(first)]
 
 
 def summarize(rows: list[dict[str, Any]]) -> dict[str, Any]:
-    reasons: dict[str, int] = {}
-    by_source: dict[str, list[dict[str, Any]]] = {}
-    for row in rows:
-        reasons[row["failure_reason"]] = reasons.get(row["failure_reason"], 0) + 1
-        by_source.setdefault(str(row.get("start_source_type", "unknown")), []).append(row)
-    return {
-        "episode_count": len(rows), "success_rate": _mean([r["success"] for r in rows]), "ready_rate": _mean([r["finisher_ready_hit"] for r in rows]),
-        "dwell_success_rate": _mean([r["finisher_ready_dwell"] for r in rows]),
-        "mean_final_position_error": _mean([r["final_position_error"] for r in rows]),
-        "mean_final_orientation_error": _mean([r["final_orientation_error"] for r in rows]),
-        "mean_final_action_magnitude": _mean([r["final_action_magnitude"] for r in rows]), "mean_final_dq_norm": _mean([r["final_dq_norm"] for r in rows]),
-        "average_start_target_joint_distance": _mean([r["joint_distance_l2"] for r in rows]),
-        "average_start_target_ee_distance": _mean([r["ee_position_distance"] for r in rows]),
-        "max_successful_joint_l2": max((r["joint_distance_l2"] for r in rows if r["success"]), default=0.0), "failure_reason_counts": reasons,
-        "success_by_start_source": {src: {"episode_count": len(items), "success_rate": _mean([i["success"] for i in items])} for src, items in by_source.items()},
-    }
+    """per-split summary of the pair evaluation (eval_full_workspace_coverage.py:74-107): rates and means over the episode rows, failure
+    reasons counted, success broken down by where the start state came from"""
+    n = len(rows)
+    succ = _column(rows, "success")
+    out: dict[str, Any] = {"episode_count": n}
+    out.update({name: float(_column(rows, key).mean()) if n else 0.0 for name, key in _SUMMARY_MEANS})
+    dist = _column(rows, "joint_distance_l2")
+    out["max_successful_joint_l2"] = float(dist[succ > 0].max()) if (succ > 0).any() else 0.0
+    out["failure_reason_counts"] = {label: int(idx.size) for label, idx in _groups([r["failure_reason"] for r in rows])}
+    out["success_by_start_source"] = {label: {"episode_count": int(idx.size), "success_rate": float(succ[idx].mean())}
+                                      for label, idx in _groups([str(r.get("start_source_type", "unknown")) for r in rows])}
+    return out
 
 
 def bucket_metrics(rows: list[dict[str, Any]]) -> dict[str, dict[str, Any]]:
-    grouped: dict[str, list[dict[str, Any]]] = {}
-    for row in rows:
-        grouped.setdefault(str(row["target_bucket_id"]), []).append(row)
-    return {b: {"episode_count": len(items), "success_rate": _mean([i["success"] for i in items]), "failure_count": sum(1 for i in items if not i["success"]),
-                "mean_final_position_error": _mean([i["final_position_error"] for i in items]),
-                "mean_min_position_error": _mean([i["min_position_error"] for i in items])} for b, items in grouped.items()}
+    """success / error statistics per target bucket (what update_bucket_priorities turns into sampling priorities)"""
+    succ, final_err, min_err = _column(rows, "success"), _column(rows, "final_position_error"), _column(rows, "min_position_error")
+    return {label: {"episode_count": int(idx.size), "success_rate": float(succ[idx].mean()), "failure_count": int((succ[idx] == 0).sum()),
+                    "mean_final_position_error": float(final_err[idx].mean()), "mean_min_position_error": float(min_err[idx].mean())}
+            for label, idx in _groups([str(r["target_bucket_id"]) for r in rows])}
 
 
 def failure_reason(approach: dict[str, float], r, success: bool, dwell: bool) -> str:

