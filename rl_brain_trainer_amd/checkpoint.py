@@ -67,10 +67,50 @@ def _policy_data(ppo, env_cfg: kcfg.EnvConfig | None) -> dict[str, Any]:
         "gamma": float(cfg.gamma), "gae_lambda": float(cfg.gae_lambda), "ent_coef": float(cfg.ent_coef), "vf_coef": float(cfg.vf_coef),
         "max_grad_norm": float(cfg.max_grad_norm), "normalize_advantage": bool(cfg.normalize_advantage),
         "use_sde": False, "sde_sample_freq": -1, "target_kl": None, "clip_range_vf": None,
-        "_n_updates": int(ppo.adam_t),
-        "kp1_engine": {"writer": "rl_brain_trainer_amd.checkpoint", "needs": "tools/finish_sb3_zip.py on a host with stable-baselines3==" + SB3_VERSION_PIN,
-                       "mode": env_cfg.mode_name if env_cfg else None},
+        # SB3: self._n_updates += self.n_epochs once per train() call (ppo.py train()); the Adam step count lives in policy.optimizer.pth
+        "_n_updates": int(getattr(ppo, "n_train_calls", 0)) * int(cfg.n_epochs),
+        # the rest of BaseAlgorithm / OnPolicyAlgorithm.__dict__ as SB3 2.8 saves it (values a freshly constructed model holds)
+        "device": "auto", "verbose": 0, "_num_timesteps_at_start": 0, "action_noise": None, "start_time": 0, "tensorboard_log": None,
+        "_last_obs": None, "_last_episode_starts": None, "_last_original_obs": None, "_episode_num": 0, "_current_progress_remaining": 1.0,
+        "_stats_window_size": 100, "ep_info_buffer": None, "ep_success_buffer": None,
+        "rollout_buffer_class": {":type:": "<class 'abc.ABCMeta'>", "__module__": "stable_baselines3.common.buffers", "__name__": "DictRolloutBuffer",
+                                 ":serialized:": None},
+        "rollout_buffer_kwargs": {},
+        "kp1_engine": {"writer": "rl_brain_trainer_amd.checkpoint", "sb3_loadable": False,
+                       "needs": "tools/finish_sb3_zip.py on a host with stable-baselines3==" + SB3_VERSION_PIN,
+                       "adam_steps": int(ppo.adam_t), "mode": env_cfg.mode_name if env_cfg else None},
     }
+
+
+# every key stable-baselines3 2.8.0 writes into the `data` member of a PPO("MultiInputPolicy") archive (BaseAlgorithm.save: __dict__ minus the
+# excluded attributes); tests/test_host_logic.py checks the writer covers them with JSON-typed values
+SB3_PPO_DATA_KEYS = (
+    "policy_class", "device", "verbose", "policy_kwargs", "num_timesteps", "_total_timesteps", "_num_timesteps_at_start", "seed", "action_noise",
+    "start_time", "learning_rate", "tensorboard_log", "_last_obs", "_last_episode_starts", "_last_original_obs", "_episode_num", "use_sde",
+    "sde_sample_freq", "_current_progress_remaining", "_stats_window_size", "ep_info_buffer", "ep_success_buffer", "_n_updates", "observation_space",
+    "action_space", "n_envs", "n_steps", "gamma", "gae_lambda", "ent_coef", "vf_coef", "max_grad_norm", "rollout_buffer_class", "rollout_buffer_kwargs",
+    "batch_size", "n_epochs", "clip_range", "clip_range_vf", "normalize_advantage", "target_kl", "lr_schedule",
+)
+PICKLED_MEMBERS = ("policy_class", "observation_space", "action_space", "lr_schedule", "clip_range", "rollout_buffer_class")
+
+
+def sb3_loadable(path: str | Path) -> bool:
+    """True when every entry SB3's loader unpickles (policy class, spaces, schedules) carries its cloudpickle payload, i.e. the archive was
+    written by SB3 itself or completed by tools/finish_sb3_zip.py.  Archives straight out of ``save`` here return False: they hold exact
+    tensors and plain descriptions, readable by this package's loaders, but ``stable_baselines3.PPO.load`` would stop at the first
+    ``":serialized:": null``."""
+    data = load_data(path)
+    return all(isinstance(data.get(k), dict) and isinstance(data[k].get(":serialized:"), str) for k in PICKLED_MEMBERS if k in data) and \
+        not (isinstance(data.get("kp1_engine"), dict) and data["kp1_engine"].get("sb3_loadable") is False)
+
+
+def require_sb3_loadable(path: str | Path) -> Path:
+    """for hand-over points where the consumer is SB3 itself (the Gazebo / RViz demo, final_codes_docker/model_manifest.yaml): refuse an
+    archive that still needs tools/finish_sb3_zip.py instead of letting PPO.load fail on the demo box"""
+    if not sb3_loadable(path):
+        raise ValueError(f"{path}: written by the MI355X engine and not yet completed for stable_baselines3.PPO.load -- run "
+                         f"tools/finish_sb3_zip.py on a host with stable-baselines3=={SB3_VERSION_PIN} (SB3 compatibility is unverified in this image)")
+    return Path(path)
 
 
 def _torch_bytes(obj: Any) -> bytes:
@@ -148,3 +188,15 @@ def load_data(path: str | Path) -> dict[str, Any]:
 
 def hidden_from_state_dict(sd: dict[str, torch.Tensor]) -> int:
     return int(sd["mlp_extractor.policy_net.0.weight"].shape[0])
+
+
+def hidden_for_run(requested: int, resume_path: str | Path | None) -> int:
+    """Width of the actor-critic for a trainer run: the checkpoint's when the run resumes from one (``PPO.load`` rebuilds the policy the zip
+    describes -- a reference-trained archive is SB3's default 2x64, train_workspace_expansion.py:187-199), else the requested width."""
+    if resume_path and Path(resume_path).exists():
+        hidden = hidden_from_state_dict(load_policy_state_dict(resume_path))
+        if hidden != int(requested):
+            print(f"[checkpoint] {resume_path} holds a 2x{hidden} policy: using that width instead of --hidden {requested}")
+        return hidden
+    return int(requested)
+

@@ -1225,8 +1225,11 @@ int kp1_mlp_create_ex(int32_t device, int32_t hidden, int32_t obs_dim, int32_t m
   if (!out || hidden <= 0 || hidden > 1024 || max_batch <= 0) return fail(KP1_ERR_INVALID, "bad argument to kp1_mlp_create");
   if (obs_dim != KP1_MLP_IN && obs_dim != KP1_MLP_IN_ROUTE)
     return fail(KP1_ERR_UNSUPPORTED, "obs_dim must be 56 (ArmKinematicEnv) or 80 (route observation keys)");
-  if (hidden != 128 && hidden != 256)
-    return fail(KP1_ERR_UNSUPPORTED, "hidden must be 128 or 256 (MFMA kernels are instantiated for these widths; 2x256 is BASELINE config 2)");
+  // 256: the fused tile path (BASELINE config 2).  128 and 64 (SB3's default net_arch, what the reference trains and what its checkpoints
+  // hold): the layer-wise MFMA kernels on a 128-wide padded layout -- padded hidden units have zero weights and biases, so they stay at
+  // tanh(0) = 0 in the forward pass and receive exactly zero gradient; finalize / Adam / the gradient norm only ever touch the H real rows.
+  if (hidden != 64 && hidden != 128 && hidden != 256)
+    return fail(KP1_ERR_UNSUPPORTED, "hidden must be 64 (SB3 default), 128 or 256 (the widths the MFMA kernels are instantiated for)");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(KP1_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
   if (device < 0 || device >= count) return fail(KP1_ERR_INVALID, "device index out of range");

@@ -254,7 +254,8 @@ class PPO:
         self.adam_m = torch.zeros_like(self.policy.flat)
         self.adam_v = torch.zeros_like(self.policy.flat)
         self.adam_t = 0
-        self.actor_extra_steps = 0     # optimiser steps only the actor tensors took (teacher-anchor side updates)
+        self.n_train_calls = 0         # train() calls so far: SB3's _n_updates = n_train_calls * n_epochs
+        self.actor_extra_steps = 0    # optimiser steps only the actor tensors took (teacher-anchor side updates)
         self._epoch_warm = False       # one eager epoch has run (kernel attributes set, code objects loaded) before the epoch graph is captured
         self.curriculum = curriculum
         if curriculum is not None:
@@ -382,6 +383,9 @@ class PPO:
             if restore_timesteps:
                 self.num_timesteps = int(data.get("num_timesteps", 0))
                 restored["num_timesteps"] = self.num_timesteps
+                saved_epochs = data.get("n_epochs")
+                if isinstance(data.get("_n_updates"), int) and isinstance(saved_epochs, int) and saved_epochs > 0:
+                    self.n_train_calls = int(data["_n_updates"]) // saved_epochs   # SB3: _n_updates += n_epochs per train() call
             if restore_hyperparameters:
                 if self._epoch_graph is not None or self.adam_t != restored.get("adam_steps", self.adam_t):
                     raise RuntimeError("restore_hyperparameters must happen before the first update")
@@ -567,6 +571,7 @@ class PPO:
         local_bs = max(cfg.batch_size // world, 1)
         stats = torch.zeros(4, device=self.device)
         n_updates = 0
+        self.n_train_calls += 1
         if self._mlp is not None:
             self.stats_dev.zero_()
         for _epoch in range(cfg.n_epochs):
@@ -696,10 +701,19 @@ class PPO:
             b1, b2 = 0.9, 0.999
             self.adam_m.mul_(b1).add_(grad, alpha=1 - b1)
             self.adam_v.mul_(b2).addcmul_(grad, grad, value=1 - b2)
-            bc1 = 1 - b1 ** self.adam_t
-            bc2 = 1 - b2 ** self.adam_t
-            denom = (self.adam_v.sqrt() / math.sqrt(bc2)).add_(cfg.adam_eps)
-            self.policy.flat.addcdiv_(self.adam_m, denom, value=-cfg.learning_rate / bc1)
+            # torch.optim.Adam counts steps per tensor: the actor tensors are `actor_extra_steps` ahead after teacher-anchor side updates
+            steps = torch.full_like(self.policy.flat, float(self.adam_t))
+            if self.actor_extra_steps:
+                off = 0
+                for name, shape in self.policy.spec:
+                    n = math.prod(shape)
+                    if name.startswith(("mlp_extractor.policy_net", "action_net")):
+                        steps[off:off + n] += float(self.actor_extra_steps)
+                    off += n
+            bc1 = 1 - b1 ** steps
+            bc2 = 1 - b2 ** steps
+            denom = (self.adam_v.sqrt() / bc2.sqrt()).add_(cfg.adam_eps)
+            self.policy.flat.sub_(cfg.learning_rate * self.adam_m / (bc1 * denom))
 
     # ------------------------------------------------------------------ driver
     def learn(self, total_timesteps: int | None = None, log_every: int = 0) -> "PPO":
@@ -729,12 +743,12 @@ class InferencePolicy:
         self.obs_dim = obs_dim
         self.policy = ActorCritic(hidden, self.device, obs_dim=obs_dim)
         self.policy.load_state_dict(state_dict)
-        self._mlp = None
-        if hidden in (128, 256):
-            from . import mlp as _mlp
+        from . import mlp as _mlp
 
-            self._mlp = _mlp.MlpKernels(hidden, self.device, max_batch=max_batch, obs_dim=obs_dim)
-            self._mlp.pack(self.policy.flat)
+        # 2x64 (SB3's default, what reference-trained archives hold), 2x128 and 2x256 all evaluate on the MFMA kernels; any other width is
+        # refused by kp1_mlp_create_ex -- there is no torch fallback in the product path
+        self._mlp = _mlp.MlpKernels(hidden, self.device, max_batch=max_batch, obs_dim=obs_dim)
+        self._mlp.pack(self.policy.flat)
 
     @classmethod
     def load(cls, path: str, device: torch.device | int = 0, max_batch: int = 8192) -> "InferencePolicy":
@@ -746,10 +760,7 @@ class InferencePolicy:
     def predict(self, obs: torch.Tensor, deterministic: bool = True) -> torch.Tensor:
         if not deterministic:
             raise NotImplementedError("evaluators use deterministic=True")
-        if self._mlp is not None:
-            mean, _ = self._mlp.mean_value(obs.contiguous())
-        else:
-            mean, _ = mlp_forward(self.policy.views, obs[:, :self.obs_dim].contiguous())
+        mean, _ = self._mlp.mean_value(obs.contiguous())
         return mean.clamp(-1.0, 1.0)
 
     __call__ = predict

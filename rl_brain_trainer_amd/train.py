@@ -146,9 +146,10 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
                                      initial_stage_index=int(ws.get("start_stage_index", 0)), device=local_rank)
     batch = args.batch_size or max(n_envs * args.n_steps * world // 64, 64)
     model_kwargs = {k: v for k, v in algo.items() if k not in ("total_timesteps", "n_steps", "batch_size")}
-    pcfg = PPOConfig.from_algo_kwargs(model_kwargs, n_steps=args.n_steps, batch_size=batch, hidden=args.hidden)
-    ppo = PPO(env, pcfg, curriculum=curriculum, dist=Dist(), backend="hip" if args.hidden in (128, 256) else "torch")
     resume = args.resume_from or ws.get("init_approach_checkpoint", "")
+    hidden = checkpoint.hidden_for_run(args.hidden, resume)     # a reference-trained zip is 2x64: the model takes the checkpoint's width
+    pcfg = PPOConfig.from_algo_kwargs(model_kwargs, n_steps=args.n_steps, batch_size=batch, hidden=hidden)
+    ppo = PPO(env, pcfg, curriculum=curriculum, dist=Dist(), backend="hip")     # 2x64 / 2x128 / 2x256 all run on the MFMA kernels
     if resume and Path(resume).exists():
         # PPO.load(resume, env=vec_env): weights, Adam state and the saved algorithm constants; the YAML's learning rate is re-applied
         ppo.load_checkpoint(resume, restore_hyperparameters=True)
@@ -202,7 +203,7 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
                 if (root / "final_eval" / name).exists():
                     shutil.copyfile(root / "final_eval" / name, root / name)
         summary = {
-            "policy_type": "approach", "algorithm": "ppo", "run_id": args.run_id, "model_path": str(latest) + ".zip",
+            "policy_type": "approach", "algorithm": "ppo", "run_id": args.run_id, "checkpoint_format": {"layout": "stable-baselines3 zip", "sb3_loadable": False, "finish_with": "tools/finish_sb3_zip.py (needs stable-baselines3==2.8.0)"}, "model_path": str(latest) + ".zip",
             "resume_from": str(resume) if resume else None, "n_envs": n_envs * world, "device": f"{world}x MI355X",
             "curriculum_summary": curriculum.summary() if curriculum is not None else None,
             "final_workspace_eval": final_eval, "num_timesteps": ppo.num_timesteps, "wall_seconds": wall,

@@ -86,14 +86,14 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
     env = ArmKinematicVecEnv(env_cfg, n_envs, device=local_rank, seed=seed, first_env_id=rank * n_envs)
     batch = args.batch_size or max(n_envs * args.n_steps * world // 64, 64)
     model_kwargs = {k: v for k, v in algo.items() if k not in ("total_timesteps", "n_steps", "batch_size")}
-    pcfg = PPOConfig.from_algo_kwargs(model_kwargs, n_steps=args.n_steps, batch_size=batch, hidden=args.hidden)
+    pcfg = PPOConfig.from_algo_kwargs(model_kwargs, n_steps=args.n_steps, batch_size=batch, hidden=checkpoint.hidden_for_run(args.hidden, args.resume_from))
     # training.dock_reverse_curriculum (train_dock_td3_policy.py:121-129): a device tracker after every env step, inside the rollout hipGraph
     curriculum = None
     cur_cfg = runtime.get("dock_reverse_curriculum", {}) or {}
     if bool(cur_cfg.get("enabled", False)):
         curriculum = DockReverseCurriculum(stages=list(cur_cfg.get("stages", [])), window_episodes=int(cur_cfg.get("window_episodes", 100)),
                                            handoff_base_dirs=base_dirs)
-    ppo = PPO(env, pcfg, curriculum=curriculum, dist=Dist(), backend="hip" if args.hidden in (128, 256) else "torch")
+    ppo = PPO(env, pcfg, curriculum=curriculum, dist=Dist(), backend="hip")
     if args.resume_from and Path(args.resume_from).exists():
         # PPO.load(resume, env=vec_env) + learn(reset_num_timesteps=False) (train_dock_policy.py:89-102)
         ppo.load_checkpoint(args.resume_from, restore_timesteps=True, restore_hyperparameters=True)
@@ -120,7 +120,7 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
         eval_summary = evaluate_dock(ppo, env_cfg, episodes=args.eval_episodes, seed=seed + 10_000, device=local_rank)
         (root / "dock_eval").mkdir(exist_ok=True)
         (root / "dock_eval" / "dock_eval_summary.json").write_text(json.dumps(eval_summary, indent=2))
-        summary = {"policy_type": "dock", "algorithm": "ppo", "run_id": args.run_id, "config": cfg, "model_path": str(latest) + ".zip",
+        summary = {"policy_type": "dock", "algorithm": "ppo", "run_id": args.run_id, "checkpoint_format": {"layout": "stable-baselines3 zip", "sb3_loadable": False, "finish_with": "tools/finish_sb3_zip.py (needs stable-baselines3==2.8.0)"}, "config": cfg, "model_path": str(latest) + ".zip",
                    "resume_from": str(args.resume_from) if args.resume_from else None, "n_envs": n_envs * world, "device": f"{world}x MI355X",
                    "dock_eval_summary": eval_summary, "dock_reverse_curriculum": curriculum.summary() if curriculum is not None else None,
                    "num_timesteps": ppo.num_timesteps, "wall_seconds": wall, "env_steps_per_second": ppo.num_timesteps / wall}

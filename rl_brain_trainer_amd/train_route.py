@@ -84,11 +84,10 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
     model_kwargs = {k: v for k, v in algo.items() if k not in ("total_timesteps", "n_steps", "batch_size")}
     n_steps = int(args.n_steps or algo.get("n_steps", 2048))
     batch = int(args.batch_size or algo.get("batch_size", 64))
-    pcfg = PPOConfig.from_algo_kwargs(model_kwargs, n_steps=n_steps, batch_size=batch, hidden=args.hidden)
+    pcfg = PPOConfig.from_algo_kwargs(model_kwargs, n_steps=n_steps, batch_size=batch, hidden=checkpoint.hidden_for_run(args.hidden, init_checkpoint))
     # the prefix curriculum: a device tracker after every env step (the rollout stays one hipGraph replay)
-    hip = args.hidden in (128, 256)
     curriculum = RoutePrefixCurriculumDevice.from_config(cfg, W)
-    ppo = PPO(env, pcfg, curriculum=curriculum, dist=Dist(), backend="hip" if hip else "torch")
+    ppo = PPO(env, pcfg, curriculum=curriculum, dist=Dist(), backend="hip")
     if init_checkpoint:
         # PPO.load(..., env=vec_env) + learn(reset_num_timesteps=False): weights, Adam state, step clock; the YAML's learning rate wins
         ppo.load_checkpoint(init_checkpoint, restore_timesteps=True, restore_hyperparameters=True)
@@ -151,7 +150,7 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
                 gate_summary["accepted_model_path"] = str(dst)
     summary = {
         "schema_version": "v5.route_curriculum.training_summary.v1", "run_id": args.run_id, "route_path": str(route_path),
-        "init_checkpoint": str(init_checkpoint) if init_checkpoint else None, "model_path": str(latest), "n_envs": n_envs, "device": "MI355X",
+        "init_checkpoint": str(init_checkpoint) if init_checkpoint else None, "checkpoint_format": {"layout": "stable-baselines3 zip", "sb3_loadable": False, "finish_with": "tools/finish_sb3_zip.py (needs stable-baselines3==2.8.0)"}, "model_path": str(latest), "n_envs": n_envs, "device": "MI355X",
         "curriculum_summary": curriculum_summary, "teacher_anchor_summary": anchor.summary() if anchor is not None else {"enabled": False},
         "route_eval_sequential_summary": eval_summary, "route_gate_summary": gate_summary, "config": cfg,
         "num_timesteps": int(ppo.num_timesteps), "wall_seconds": wall, "env_steps_per_second": (ppo.num_timesteps - start_steps) / max(wall, 1e-9),

@@ -75,7 +75,42 @@ BUILTIN = {
     "workspace_expansion_1h_extend": ("workspace", "workspace_expansion_1h_extend.yaml"),
     "workspace_full_coverage_randomstart_overnight": ("workspace", "workspace_full_coverage_randomstart_overnight.yaml"),
     "dock_default": ("dock", None),
+    # the fine-tuning chain behind the reference's published Stage-5 figure, and the Approach settle config
+    "workspace_expansion_dynamic_scale_big": ("workspace", "workspace_expansion_dynamic_scale_big.yaml"),
+    "workspace_expansion_late_stage_ft": ("workspace", "workspace_expansion_late_stage_ft.yaml"),
+    "approach_finisher_ready_v2_settle": ("workspace", "approach_finisher_ready_v2_settle.yaml"),
 }
+ROUTE_BUILTIN = ("route_curriculum_default", "route_curriculum_prefix20_sequence2", "route_curriculum_prefix120_routeobs_sequence2")
+
+
+@pytest.mark.parametrize("name", ROUTE_BUILTIN)
+def test_builtin_route_yaml_resolves_to_reference_config(name):
+    """route configs: the whole merged dict (env, algorithms, route block) equals the reference's resolved config"""
+    cfg = kcfg.load_workspace_expansion_config(kcfg.builtin_config_dir() / f"{name}.yaml")
+    gold_cfg = json.loads((GOLDEN / "configs" / f"{name}.json").read_text())
+    assert cfg == gold_cfg
+    assert bytes(kcfg.to_env_config(cfg).c) == bytes(kcfg.to_env_config(gold_cfg).c)
+
+
+def test_checkpoint_data_member_has_every_sb3_key():
+    """the `data` member of a written zip must carry every key stable-baselines3 2.8 saves, JSON-typed, and say in a
+    machine-readable way that the pickled members still need tools/finish_sb3_zip.py (PPO.load compatibility itself is unpinned: SB3 is
+    not importable here)."""
+    from types import SimpleNamespace
+
+    from rl_brain_trainer_amd import checkpoint as ck
+    from rl_brain_trainer_amd.ppo import PPOConfig
+
+    fake = SimpleNamespace(cfg=PPOConfig(hidden=64, n_epochs=8), n_envs=12, dist=SimpleNamespace(world_size=1), num_timesteps=24576, adam_t=384,
+                           n_train_calls=1, obs_dim=56)
+    data = ck._policy_data(fake, None)
+    assert set(ck.SB3_PPO_DATA_KEYS) <= set(data)
+    json.loads(json.dumps(data))                                   # JSON-typed all the way down
+    assert data["_n_updates"] == 8 and data["kp1_engine"]["adam_steps"] == 384     # SB3 counts n_epochs per train() call, not Adam steps
+    assert data["policy_kwargs"] == {} and data["kp1_engine"]["sb3_loadable"] is False
+    assert all(data[k][":serialized:"] is None for k in ck.PICKLED_MEMBERS)
+    fake.cfg = PPOConfig(hidden=256)
+    assert ck._policy_data(fake, None)["policy_kwargs"] == {"net_arch": {"pi": [256, 256], "vf": [256, 256]}}
 
 
 @pytest.mark.parametrize("name", sorted(BUILTIN))

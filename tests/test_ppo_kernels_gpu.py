@@ -373,13 +373,16 @@ def test_ppo_optimiser_step_matches_cpu_oracle():
     k.close()
 
 
+@pytest.mark.parametrize("hidden", [128, 64])
 @pytest.mark.parametrize("obs_dim", [56, 80])
-def test_hidden128_layerwise_path(obs_dim):
-    """net_arch 2x128 (the other width the MFMA kernels are instantiated for) runs through the layer-wise kernels: forward and
-    loss / gradient against torch, both observation widths."""
+def test_hidden128_layerwise_path(obs_dim, hidden):
+    """net_arch 2x128 and 2x64 -- SB3's default, the width the reference trains (train_workspace_expansion.py:199, no policy_kwargs) and its
+    checkpoints hold -- run through the layer-wise MFMA kernels (2x64 on a zero-padded 128-wide layout): forward, loss / gradient and the
+    optimiser step against torch, both observation widths."""
     D, W = obs_dim, (64 if obs_dim <= 64 else 128)
-    pol = _policy(hidden=128, scale_heads=False, obs_dim=D)
-    k = MlpKernels(128, DEV, max_batch=8192, obs_dim=D)
+    pol = _policy(hidden=hidden, scale_heads=False, obs_dim=D)
+    k = MlpKernels(hidden, DEV, max_batch=8192, obs_dim=D)
+    assert k.num_params == pol.flat.numel()
     k.pack(pol.flat)
     g = torch.Generator(device=DEV).manual_seed(21)
     total, n = 9000, 5000
@@ -409,11 +412,40 @@ def test_hidden128_layerwise_path(obs_dim):
         off += cnt
     # optimiser step + repack keep the layer-wise weight copies current
     m, v = torch.zeros_like(pol.flat), torch.zeros_like(pol.flat)
+    before = pol.flat.clone()
     k.adam_step(pol.flat, grad, m, v, lr=1e-3, eps=1e-5, max_grad_norm=0.5, step=1)
+    # clip_grad_norm_(0.5) + Adam step 1 in torch on the reference gradient: the padded units of the 2x64 layout must not leak into the norm
+    gref = ref * torch.clamp(0.5 / (torch.linalg.vector_norm(ref) + 1e-6), max=1.0)
+    expect = before - 1e-3 * (0.1 * gref / (1 - 0.9)) / ((0.001 * gref * gref).sqrt() / math.sqrt(1 - 0.999) + 1e-5)
+    big = gref.abs() > 1e-3 * gref.abs().max()          # where g ~ 0 Adam's sign(g) step amplifies rounding noise
+    assert (pol.flat - expect)[big].abs().max().item() <= 2e-5
     mean2, _ = k.mean_value(obs[:512].contiguous())
     m2, _ = P.mlp_forward(pol.views, obs[:512, :D].contiguous())
     assert torch.allclose(mean2, m2, rtol=1e-4, atol=2e-5)
     k.close()
+
+
+def test_reference_width_policy_trains_on_hip_backend():
+    """PPO with SB3's default 2x64 policy (PPOConfig.hidden default) uses the HIP backend end to end: rollout, update, checkpoint round trip
+    through InferencePolicy -- no torch backend in the product path."""
+    from conftest import load_golden_config
+    from rl_brain_trainer_amd.vec_env import ArmKinematicVecEnv
+
+    env = ArmKinematicVecEnv(load_golden_config("workspace_expansion_bigtrain"), 256, seed=806)
+    env.set_curriculum_stage(5)
+    ppo = P.PPO(env, P.PPOConfig(n_steps=32, batch_size=2048, n_epochs=2, learning_rate=3e-4, seed=1), backend="hip")
+    assert ppo.cfg.hidden == 64 and ppo._mlp is not None
+    before = ppo.policy.flat.clone()
+    for _ in range(3):
+        ppo.collect_rollouts()
+        ppo.train()
+    torch.cuda.synchronize()
+    assert torch.isfinite(ppo.policy.flat).all() and (ppo.policy.flat != before).any()
+    pol = P.InferencePolicy(ppo.policy.state_dict())
+    obs = ppo.obs_buf[0, :64].contiguous()
+    ref, _ = P.mlp_forward(ppo.policy.views, obs[:, :56].contiguous())
+    assert torch.allclose(pol.predict(obs), ref.clamp(-1, 1), rtol=1e-4, atol=2e-5)
+    env.close()
 
 
 @pytest.mark.parametrize("mode", ["raw", "given"])

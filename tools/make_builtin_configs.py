@@ -92,6 +92,29 @@ def main() -> None:
          "Random-start mixed-workspace run (BASELINE config 4): overlay on workspace_expansion_1h_extend.yaml.\n"
          "Values: reference kinematic_phase1/configs/workspace_full_coverage_randomstart_overnight.yaml.",
          base_config="workspace_expansion_1h_extend.yaml")
+    # the fine-tuning chain the reference's published Stage-5 figure comes from (report/OFFICIAL_ARTIFACTS.md): bigtrain -> 1h_extend ->
+    # dynamic_scale_big -> late_stage_ft, each resumed from the previous run's checkpoint with its own (lower) learning rate
+    dyn = load("workspace_expansion_dynamic_scale_big")
+    emit("workspace_expansion_dynamic_scale_big.yaml", diff(dyn, ext),
+         "Stage 0-11 fine-tuning with the dynamic action-delta scale (far/near multipliers): overlay on workspace_expansion_1h_extend.yaml.\n"
+         "Values: reference kinematic_phase1/configs/workspace_expansion_dynamic_scale_big.yaml.",
+         base_config="workspace_expansion_1h_extend.yaml")
+    late = load("workspace_expansion_late_stage_ft")
+    emit("workspace_expansion_late_stage_ft.yaml", diff(late, ext),
+         "Late-stage fine-tuning (stage sampling weighted to the current / previous stages): overlay on workspace_expansion_1h_extend.yaml.\n"
+         "Values: reference kinematic_phase1/configs/workspace_expansion_late_stage_ft.yaml.",
+         base_config="workspace_expansion_1h_extend.yaml")
+    settle = load("approach_finisher_ready_v2_settle")
+    emit("approach_finisher_ready_v2_settle.yaml", diff(settle, base),
+         "Approach fine-tune towards the finisher-ready zone with settle bonuses: overlay on approach_default <- ppo_default.\n"
+         "Values: reference kinematic_phase1/configs/approach_finisher_ready_v2_settle.yaml.")
+    for route_name, note in (("route_curriculum_default", "Route curriculum defaults (single-waypoint wrapper, 56-float observation)."),
+                             ("route_curriculum_prefix20_sequence2", "Route curriculum, prefix 20, sequence-2 wrapper."),
+                             ("route_curriculum_prefix120_routeobs_sequence2",
+                              "Route curriculum, prefix 120, sequence-2 wrapper, 80-float route observation (BASELINE config 5 moves the window to 170).")):
+        route = load(route_name)
+        emit(f"{route_name}.yaml", diff(route, base), note + "  Overlay on approach_default <- ppo_default.\n"
+             f"Values: reference kinematic_phase1/configs/{route_name}.yaml.")
     fin = load("dock_workspace_handoff_noop_ft_12env_raw")
     fin["env"]["dock_reset"]["handoff_state_buffer_path"] = ""
     emit("dock_workspace_handoff_noop_ft_12env.yaml", fin,
