@@ -57,16 +57,19 @@ __device__ unsigned long long kp1_nt_trace_buf[KP1_TRACE_SLOTS * KP1_TRACE_WGS];
 #define KP1_TR_HW(slot)
 #endif
 
-// Branch-free tanh (the epilogue runs one wave per SIMD, so every VALU slot is exposed; ocml's tanhf costs ~45
-// instructions plus divergent branches).  |x| < 0.25: odd Taylor polynomial through x^9 (truncation < 1e-8 relative);
-// else 1 - 2 / (2^(2 log2(e) |x|) + 1) on v_exp_f32 / v_rcp_f32.  Absolute error <= ~2e-7 (fp32 rounding of values near 1),
-// checked against torch.tanh in tests/test_ppo_kernels_gpu.py.
+// tanh(x) = 2 / (1 + 2^(-2 log2(e) x)) - 1 in FIVE vector instructions (v_mul, v_exp_f32, v_add, v_rcp_f32, v_fma = 28 issue cycles).
+// Instruction count matters more here than anywhere else in the kernel: v_mfma_f32_32x32x2_f32 runs on the SIMD's fp32 FMA lanes, so
+// vector-ALU work never overlaps with fp32 MFMAs -- not inside a wave (one v_fma between two MFMAs costs its full 4 cycles on top of the
+// MFMA's 64) and not across co-resident waves (a VALU-only wave next to an MFMA-only wave finishes in the SUM of both times);
+// tools/mfma_valu_mix.hip, profiles/r02_mfma_valu_mix.log.  Every vector instruction of an epilogue is therefore paid in MFMA time, and
+// the 64 tanh evaluations per lane were 38 % of the tile kernel's vector instructions in the round-1 form (14 instructions each: odd
+// polynomial below |x| = 0.25, exp form above, select, copysign).  Saturates correctly (2^(+big) = inf -> -1, 2^(-big) = 0 -> +1), NaN
+// propagates.  Absolute error <= ~1.5e-7 everywhere (the rounding of 1 + t and of the final 2r - 1), i.e. fp32 epsilon of the result's
+// scale; the RELATIVE error grows as |x| -> 0 (result ~ x +- 1e-7), which a tanh hidden unit's consumers -- dot products of 256 such
+// values, and 1 - h^2 in the backward pass -- do not resolve.  Checked against torch.tanh in tests/test_ppo_kernels_gpu.py.
 __device__ __forceinline__ float kp_tanh(float x) {
-  const float ax = fabsf(x), x2 = x * x;
-  const float small = ax * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 0.021869488536155203f, -0.05396825396825397f), 0.13333333333333333f), -0.3333333333333333f), 1.0f);
-  const float t = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);
-  const float big = fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
-  return copysignf(ax < 0.25f ? small : big, x);
+  const float t = __builtin_amdgcn_exp2f(x * -2.8853900817779268f);
+  return fmaf(2.0f, __builtin_amdgcn_rcpf(t + 1.0f), -1.0f);
 }
 
 struct GemmNT {
@@ -857,23 +860,56 @@ __device__ __forceinline__ int64_t finalize_wide_index(const ParamLayout& L, int
   return L.a_w + e;
 }
 
-// Blocks [0, n_main): one thread per flat element; the weight matrices (few partials per element: one per batch chunk of
-// the TN GEMMs) are summed by their thread, "wide" elements are skipped.  Blocks [n_main, ...): 32 wide elements each, 8
-// threads per element walk the per-tile partials with a stride of 8 (32 loads in flight each) and LDS combines the 8
-// strands in a fixed order -- a single thread summing 256 tiles was the tail of this kernel (8 dependent load rounds).
+// Blocks [0, n_main): the four weight matrices (dW2, dW1 of both nets; few partials per element: one per batch chunk of the TN GEMMs).
+// One thread owns FOUR consecutive columns of one weight row and sums its float4 partials over the chunks with all loads in flight: a
+// quarter of the load instructions of a thread-per-element walk over the same 25 MB (the kernel is bound by load issue + latency, not
+// bandwidth), same summation order per element (chunk 0, 1, 2, ...).  Blocks [n_main, ...): 32 "wide" elements each (biases, heads,
+// log_std: one partial per 32-row tile), 8 threads per element walk the per-tile partials with a stride of 8 (32 loads in flight each) and
+// LDS combines the 8 strands in a fixed order -- a single thread summing 256 tiles was the tail of this kernel (8 dependent load rounds).
 // Every block leaves the sum of squares of what it wrote in sumsq[blockIdx.x] for clip_grad_norm_.
+__host__ __device__ inline int64_t finalize_vec_items(const ParamLayout& L) { return 2 * ((int64_t)L.H * L.H / 4 + (int64_t)L.H * L.IN / 4); }
+
 __global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a, int n_main) {
   const ParamLayout& L = a.L;
   __shared__ double sq[256];
   __shared__ float red[8][32];
   float gval = 0.f;
+  double gsq = 0.0;
   if ((int)blockIdx.x < n_main) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < L.total) {
-      const PartialSrc s = finalize_source(a, i);
-      if (!s.wide) {
-        gval = sum_strided<32>(s.p, s.stride, s.n);
-        a.grad[i] = gval;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t per2 = (int64_t)L.H * L.H / 4, per1 = (int64_t)L.H * L.IN / 4;
+    if (j < 2 * (per2 + per1)) {
+      const float* src;
+      int64_t stride, dst;
+      int n;
+      if (j < 2 * per2) {
+        const int net = j >= per2;
+        const int64_t rem = j - net * per2, row = rem / (L.H / 4), c4 = rem % (L.H / 4);
+        src = a.slab2 + net * a.s2_net + row * a.s2_ld + 4 * c4;
+        stride = a.s2_chunk; n = a.s2_n;
+        dst = (net ? L.v_w2 : L.p_w2) + row * L.H + 4 * c4;
+      } else {
+        const int64_t k = j - 2 * per2;
+        const int net = k >= per1;
+        const int64_t rem = k - net * per1, row = rem / (L.IN / 4), c4 = rem % (L.IN / 4);
+        src = a.slab1 + net * a.s1_net + row * a.s1_ld + 4 * c4;
+        stride = a.s1_chunk; n = a.s1_n;
+        dst = (net ? L.v_w1 : L.p_w1) + row * L.IN + 4 * c4;
+      }
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      int c = 0;
+      for (; c + 16 <= n; c += 16) {
+        f32x4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(c + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+      }
+      for (; c < n; ++c) s += *reinterpret_cast<const f32x4*>(src + (int64_t)c * stride);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a.grad[dst + q] = s[q];
+        gsq += (double)s[q] * (double)s[q];
       }
     }
     if (a.step_counter && blockIdx.x == 0 && threadIdx.x == 0) *a.step_counter += 1;  // read by the adam kernel that follows
@@ -924,7 +960,7 @@ __global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a
       }
     }
   }
-  sq[threadIdx.x] = (double)gval * (double)gval;
+  sq[threadIdx.x] = gsq + (double)gval * (double)gval;
   __syncthreads();
   for (int k = 128; k > 0; k >>= 1) {
     if (threadIdx.x < k) sq[threadIdx.x] += sq[threadIdx.x + k];
@@ -1162,7 +1198,7 @@ int launch_tn_frag(const TnFragArgs& t, hipStream_t stream) {
   if (t.n_chunks2 > 64 || t.n_chunks1 > 64) return fail(KP1_ERR_INVALID, "too many batch chunks for the partial-gradient slabs");
   const size_t bytes = sizeof(float) * 128 * (128 + 4);
   HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_frag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  hipLaunchKernelGGL(gemm_tn_frag_kernel, dim3(8 * t.n_chunks2 + 4 * t.n_chunks1), dim3(256), bytes, stream, t);
+  hipLaunchKernelGGL(gemm_tn_frag_kernel, dim3(8 * t.n_chunks2), dim3(TNF_THREADS), bytes, stream, t);
   return KP1_OK;
 }
 
@@ -1492,7 +1528,7 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   f.ent_coef = ent_coef; f.inv_count = inv_count; f.log_std = m->k.log_std;
   f.grad = grad_out; f.stats = stats_out; f.sumsq = m->partials + 2 * N_PARTIALS;
   f.step_counter = m->step_dev;
-  const int n_main = (int)((L.total + 255) / 256);
+  const int n_main = (int)((finalize_vec_items(L) + 255) / 256);
   m->n_finalize_blocks = n_main + (int)((finalize_wide_count(L) + 3 + 31) / 32);
   if (m->n_finalize_blocks > 2048) return fail(KP1_ERR_INVALID, "parameter vector too large for the sum-of-squares partial buffer");
   {

@@ -79,6 +79,11 @@ BUILTIN = {
     "workspace_expansion_dynamic_scale_big": ("workspace", "workspace_expansion_dynamic_scale_big.yaml"),
     "workspace_expansion_late_stage_ft": ("workspace", "workspace_expansion_late_stage_ft.yaml"),
     "approach_finisher_ready_v2_settle": ("workspace", "approach_finisher_ready_v2_settle.yaml"),
+    # the Approach policy's precision curriculum (3 cm -> 8 mm -> 5 mm finisher-ready)
+    "approach_workspace_default": ("workspace", "approach_workspace_default.yaml"),
+    "approach_workspace_handoff_ready_8mm_12env": ("workspace", "approach_workspace_handoff_ready_8mm_12env.yaml"),
+    "approach_workspace_handoff_ready_8mm_ft_12env": ("workspace", "approach_workspace_handoff_ready_8mm_ft_12env.yaml"),
+    "approach_finisher_ready_v1": ("workspace", "approach_finisher_ready_v1.yaml"),
 }
 ROUTE_BUILTIN = ("route_curriculum_default", "route_curriculum_prefix20_sequence2", "route_curriculum_prefix120_routeobs_sequence2")
 

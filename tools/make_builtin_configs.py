@@ -108,6 +108,13 @@ def main() -> None:
     emit("approach_finisher_ready_v2_settle.yaml", diff(settle, base),
          "Approach fine-tune towards the finisher-ready zone with settle bonuses: overlay on approach_default <- ppo_default.\n"
          "Values: reference kinematic_phase1/configs/approach_finisher_ready_v2_settle.yaml.")
+    # the precision curriculum of the Approach policy (3 cm -> 8 mm -> 5 mm finisher-ready -> settle): tests/golden/make_golden_approach_chain.py
+    for name, note in (("approach_workspace_default", "Approach, workspace variant: 30-step episodes, success at 3 cm."),
+                       ("approach_workspace_handoff_ready_8mm_12env", "Approach towards an 8 mm handoff-ready zone (40-step episodes)."),
+                       ("approach_workspace_handoff_ready_8mm_ft_12env", "Approach, 8 mm handoff-ready fine-tune (44-step episodes)."),
+                       ("approach_finisher_ready_v1", "Approach into the 5 mm / 0.05 rad finisher-ready zone (24-step episodes).")):
+        emit(f"{name}.yaml", diff(load(name), base), note + "  Overlay on approach_default <- ppo_default.\n"
+             f"Values: reference kinematic_phase1/configs/{name}.yaml.")
     for route_name, note in (("route_curriculum_default", "Route curriculum defaults (single-waypoint wrapper, 56-float observation)."),
                              ("route_curriculum_prefix20_sequence2", "Route curriculum, prefix 20, sequence-2 wrapper."),
                              ("route_curriculum_prefix120_routeobs_sequence2",

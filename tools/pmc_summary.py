@@ -1,6 +1,9 @@
 """Summarise the rocprofv3 --pmc passes of tools/pmc_passes.sh into profiles/.
 
-    python tools/pmc_summary.py gpurun_out/<dir> profiles/r01
+    python tools/pmc_summary.py gpurun_out/<dir> profiles/r01 [suffix]
+
+An optional third argument is appended to every kernel name (e.g. "@32768" for the config-3 env-kernel passes of
+tools/env_kernel_bench.py) and the records are MERGED into an existing <prefix>_pmc_traffic.json instead of replacing it.
 
 writes <prefix>_pmc_kernels.csv (per kernel: launches, FETCH_SIZE KB, WRITE_SIZE KB, L2 hits / misses, averages per launch)
 and <prefix>_pmc_traffic.json (bench.py's roofline.traffic source: HBM bytes per launch).
@@ -50,6 +53,7 @@ def collect(path: str) -> dict:
 
 def main() -> None:
     src, prefix = sys.argv[1], sys.argv[2]
+    suffix = sys.argv[3] if len(sys.argv) > 3 else ""
     merged = collections.defaultdict(dict)
     for tag in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum_TCC_MISS_sum"):
         try:
@@ -67,11 +71,20 @@ def main() -> None:
         write = c.get("WRITE_SIZE", (0, 0.0))
         hit, miss = c.get("TCC_HIT_sum", (0, 0.0))[1], c.get("TCC_MISS_sum", (0, 0.0))[1]
         hbm = fetch[1] * 1024 * 2 + write[1] * 1024
+        k = k + suffix
+        if suffix and k.startswith("kp1_step<"):
+            k = "kp1_step_kernel" + suffix            # bench.py looks the config-3 record up under this name
         rows.append([k, fetch[0], round(fetch[1], 1), round(write[1], 1), round(hit), round(miss), round(hit / (hit + miss), 3) if hit + miss else "",
                      round(hbm)])
         traffic[k] = {"hbm_bytes_per_launch": round(hbm), "fetch_size_kb_raw": fetch[1], "write_size_kb": write[1], "launches": fetch[0],
                       "correction": "FETCH_SIZE x2 (gfx950 wide-load undercount) + WRITE_SIZE"}
-    with open(prefix + "_pmc_kernels.csv", "w", newline="") as f:
+    if suffix:
+        try:
+            with open(prefix + "_pmc_traffic.json") as f:
+                traffic = {**json.load(f), **traffic}
+        except OSError:
+            pass
+    with open(prefix + "_pmc_kernels" + suffix.replace("@", "_") + ".csv", "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "launches", "FETCH_SIZE_KB_avg_raw", "WRITE_SIZE_KB_avg", "TCC_HIT_avg", "TCC_MISS_avg", "L2_hit_rate", "hbm_bytes_per_launch_corrected"])
         w.writerows(rows)
