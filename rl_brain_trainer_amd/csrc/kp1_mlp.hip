@@ -1028,6 +1028,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float*
   if (zero_grad) g[i] = 0.f;
 }
 
+#include "kp1_mlp_tile.inc"
 #include "kp1_mlp_fused.inc"
 
 }  // namespace
@@ -1152,44 +1153,36 @@ int launch_nt(const GemmNT& g, hipStream_t stream) {
 // dW (both nets) = D^T X over n rows: split-B partial tiles into m->slab, then the fixed-order reduce into G
 int launch_tn(kp1_mlp* m, GemmTN t, int n_o_tiles, int slab_cols, float* slab, int* n_chunks_out, hipStream_t stream);
 
-int launch_fused(const FusedArgs& fa_in, hipStream_t stream) {
-  FusedArgs fa = fa_in;
-  static const int stagger_us = [] { const char* e = std::getenv("KP1_FU_STAGGER_US"); return e ? std::atoi(e) : 12; }();  // tuning knob
-  static const int n_cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-    return n;
-  }();
-  const int n_wgs = 2 * ((fa.n + FU_BM - 1) / FU_BM);
-  fa.n_cus = n_cus;
-  fa.stagger_ticks = n_wgs > n_cus ? stagger_us * 100 : 0;   // only when CUs hold two workgroups at once
-  const size_t bytes = sizeof(float) * FU_LDS_FLOATS;
-  const dim3 grid((fa.n + FU_BM - 1) / FU_BM, 1, 2);
+int launch_fused(const FusedArgs& fa, hipStream_t stream) {
+  using G = FuGeom<true>;   // 64-row tiles, 8 waves, one workgroup per CU
+  const size_t bytes = sizeof(float) * G::LDS_FLOATS;
+  const dim3 grid((fa.n + G::BM - 1) / G::BM, 1, 2);
   if (fa.inp == 64) {
     HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL((mlp_tile_kernel<true, 2>), grid, dim3(FU_NTH), bytes, stream, fa);
+    hipLaunchKernelGGL((mlp_tile_kernel<true, 2>), grid, dim3(G::NTH), bytes, stream, fa);
   } else {
     HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL((mlp_tile_kernel<true, 4>), grid, dim3(FU_NTH), bytes, stream, fa);
+    hipLaunchKernelGGL((mlp_tile_kernel<true, 4>), grid, dim3(G::NTH), bytes, stream, fa);
   }
   return KP1_OK;
 }
 
 int launch_fused_infer(const FusedArgs& fa, hipStream_t stream) {
-  const size_t bytes = sizeof(float) * FU_LDS_FLOATS;
+  using G = FuGeom<false>;  // 32-row tiles, 4 waves, two workgroups per CU
+  const size_t bytes = sizeof(float) * G::LDS_FLOATS;
   // the value net is skipped when no value is asked for (deterministic evaluators), the policy net when only values are
   const bool want_pi = fa.mean || fa.action || fa.clipped || fa.log_prob;
   if (!want_pi && !fa.value) return KP1_OK;
   FusedArgs f = fa;
   const bool both = want_pi && fa.value;
   if (!both) f.net_base = want_pi ? 0 : 1;
-  const dim3 grid((fa.n + FU_BM - 1) / FU_BM, 1, both ? 2 : 1);
+  const dim3 grid((fa.n + G::BM - 1) / G::BM, 1, both ? 2 : 1);
   if (fa.inp == 64) {
     HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL((mlp_tile_kernel<false, 2>), grid, dim3(FU_NTH), bytes, stream, f);
+    hipLaunchKernelGGL((mlp_tile_kernel<false, 2>), grid, dim3(G::NTH), bytes, stream, f);
   } else {
     HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL((mlp_tile_kernel<false, 4>), grid, dim3(FU_NTH), bytes, stream, f);
+    hipLaunchKernelGGL((mlp_tile_kernel<false, 4>), grid, dim3(G::NTH), bytes, stream, f);
   }
   return KP1_OK;
 }
@@ -1488,7 +1481,7 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
     t.dz2 = m->dz2; t.h1 = m->h1; t.dz1 = m->dz1; t.act_stride = act_stride; t.xf = m->xf;
     t.slab2 = m->slab; t.s2_net = (int64_t)Hp * Hp; t.s2_chunk = 2 * t.s2_net;
     t.slab1 = m->slab1; t.s1_net = (int64_t)Hp * INP; t.s1_chunk = 2 * t.s1_net;
-    t.groups = (n + FU_BM - 1) / FU_BM * (FU_BM / 8);
+    t.groups = (n + FU_BM_TRAIN - 1) / FU_BM_TRAIN * (FU_BM_TRAIN / 8);   // the tile kernel writes whole 64-row tiles
     auto up8 = [](int v) { return (v + 7) / 8 * 8; };
     t.cg2 = up8((t.groups + KP1_TN_SPLIT2 - 1) / KP1_TN_SPLIT2);   // ~32 chunks x 8 tiles = one dW2 workgroup per CU
     t.cg1 = up8((t.groups + KP1_TN_SPLIT1 - 1) / KP1_TN_SPLIT1);   // ~64 chunks x 4 tiles of quarter-size dW1 workgroups
@@ -1523,7 +1516,7 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   f.L = L;
   f.slab2 = m->slab; f.s2_ld = Hp; f.s2_net = (int64_t)Hp * Hp; f.s2_chunk = 2 * f.s2_net; f.s2_n = s2_n;
   f.slab1 = m->slab1; f.s1_ld = INP; f.s1_net = (int64_t)Hp * INP; f.s1_chunk = 2 * f.s1_net; f.s1_n = s1_n;
-  f.bslab = m->bslab; f.b_net = Hp; f.b_tile = 2 * Hp; f.b_n = fused ? (n + FU_BM - 1) / FU_BM : nt_row_tiles(n, Hp);
+  f.bslab = m->bslab; f.b_net = Hp; f.b_tile = 2 * Hp; f.b_n = fused ? (n + FU_BM_TRAIN - 1) / FU_BM_TRAIN * (FU_BM_TRAIN / 32) : nt_row_tiles(n, Hp);
   f.hpart = m->hpart; f.h_stride = 10 * Hp + 32; f.h_n = (n + HEAD_ROWS - 1) / HEAD_ROWS;
   f.ent_coef = ent_coef; f.inv_count = inv_count; f.log_std = m->k.log_std;
   f.grad = grad_out; f.stats = stats_out; f.sumsq = m->partials + 2 * N_PARTIALS;
@@ -1613,7 +1606,7 @@ int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32
         t.dz2 = m->dz2; t.h1 = m->h1; t.dz1 = m->dz1; t.act_stride = act_stride; t.xf = m->xf;
         t.slab2 = m->slab; t.s2_net = (int64_t)Hp * Hp; t.s2_chunk = 2 * t.s2_net;
         t.slab1 = m->slab1; t.s1_net = (int64_t)Hp * INP; t.s1_chunk = 2 * t.s1_net;
-        t.groups = (n + FU_BM - 1) / FU_BM * (FU_BM / 8);
+        t.groups = (n + FU_BM_TRAIN - 1) / FU_BM_TRAIN * (FU_BM_TRAIN / 8);   // the tile kernel writes whole 64-row tiles
         t.cg2 = ((t.groups + KP1_TN_SPLIT2 - 1) / KP1_TN_SPLIT2 + 7) / 8 * 8;
         t.cg1 = ((t.groups + KP1_TN_SPLIT1 - 1) / KP1_TN_SPLIT1 + 7) / 8 * 8;
         t.n_chunks2 = (t.groups + t.cg2 - 1) / t.cg2;

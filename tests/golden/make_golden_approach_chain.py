@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Resolved configs of the Approach fine-tuning lineage behind the reference's published Stage 0-5 table
 (docs/PHASE1_APPROACH_DOCK_CLOSEOUT.md:36-47: Approach config = approach_finisher_ready_v2_settle.yaml), i.e. the precision curriculum
-3 cm -> 8 mm -> 5 mm finisher-ready that its YAMLs spell out.  Build container only (imports the reference's own YAML loader, as
+3 cm -> 8 mm -> 2 cm / 0.18 rad dock-coarse-ready -> 5 mm / 0.05 rad finisher-ready that its YAMLs spell out.  Build container only (imports the reference's own YAML loader, as
 make_golden.py does); writes tests/golden/configs/<name>.json, from which tools/make_builtin_configs.py emits the builtin YAML overlays.
 
     PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden_approach_chain.py
@@ -21,7 +21,7 @@ from hrl_trainer.kinematic_phase1.training.policy_config import (  # noqa: E402
 
 OUT = Path(__file__).resolve().parent / "configs"
 CHAIN = ("approach_workspace_default", "approach_workspace_handoff_ready_8mm_12env", "approach_workspace_handoff_ready_8mm_ft_12env",
-         "approach_finisher_ready_v1")
+         "approach_dock_coarse_ready_v1", "approach_finisher_ready_v1")
 
 
 def main() -> None:

@@ -83,6 +83,7 @@ BUILTIN = {
     "approach_workspace_default": ("workspace", "approach_workspace_default.yaml"),
     "approach_workspace_handoff_ready_8mm_12env": ("workspace", "approach_workspace_handoff_ready_8mm_12env.yaml"),
     "approach_workspace_handoff_ready_8mm_ft_12env": ("workspace", "approach_workspace_handoff_ready_8mm_ft_12env.yaml"),
+    "approach_dock_coarse_ready_v1": ("workspace", "approach_dock_coarse_ready_v1.yaml"),
     "approach_finisher_ready_v1": ("workspace", "approach_finisher_ready_v1.yaml"),
 }
 ROUTE_BUILTIN = ("route_curriculum_default", "route_curriculum_prefix20_sequence2", "route_curriculum_prefix120_routeobs_sequence2")

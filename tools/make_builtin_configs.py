@@ -112,6 +112,7 @@ def main() -> None:
     for name, note in (("approach_workspace_default", "Approach, workspace variant: 30-step episodes, success at 3 cm."),
                        ("approach_workspace_handoff_ready_8mm_12env", "Approach towards an 8 mm handoff-ready zone (40-step episodes)."),
                        ("approach_workspace_handoff_ready_8mm_ft_12env", "Approach, 8 mm handoff-ready fine-tune (44-step episodes)."),
+                       ("approach_dock_coarse_ready_v1", "Approach into the 2 cm / 0.18 rad dock-coarse-ready zone (24-step episodes)."),
                        ("approach_finisher_ready_v1", "Approach into the 5 mm / 0.05 rad finisher-ready zone (24-step episodes).")):
         emit(f"{name}.yaml", diff(load(name), base), note + "  Overlay on approach_default <- ppo_default.\n"
              f"Values: reference kinematic_phase1/configs/{name}.yaml.")

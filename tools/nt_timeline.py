@@ -20,7 +20,10 @@ os.makedirs(out_dir, exist_ok=True)
 lib = os.path.join(out_dir, "libkp1_trace.so")
 srcs = [os.path.join(ROOT, "rl_brain_trainer_amd/csrc", f) for f in ("kp1_env.hip", "kp1_ppo.hip", "kp1_mlp.hip")]
 extra = [f"-D{d}" for d in os.environ.get("KP1_TRACE_DEFS", "").split() if d]   # e.g. KP1_TNF_NOMFMA, KP1_TNF_NOLOAD
-subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DKP1_NT_TRACE", "-shared", "-o", lib] + extra + srcs)
+if os.environ.get("KP1_TRACE_LIB"):      # a library already built with -DKP1_NT_TRACE (tools/ab_local.sh build trace=-DKP1_NT_TRACE)
+    lib = os.path.join(ROOT, os.environ["KP1_TRACE_LIB"])
+else:
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DKP1_NT_TRACE", "-shared", "-o", lib] + extra + srcs)
 
 import numpy as np
 import torch
@@ -87,7 +90,7 @@ if tn:
         print(f"{nm:>18}: min {col.min():7.2f}  median {np.median(col):7.2f}  max {col.max():7.2f}")
     sys.exit(0)
 if fused:
-    names = ["start", "prologue_done", "h1_in_lds", "h2_in_lds", "heads_done", "dz1_in_lds", "stores_issued"]
+    names = ["start", "prologue_done", "h1_in_lds", "h2_in_lds", "heads_done", "dz1_done", "stores_issued"]
     for i, nm in enumerate(names):
         col = us[:, i]
         print(f"{nm:>18}: min {col.min():7.2f}  median {np.median(col):7.2f}  max {col.max():7.2f}")

@@ -36,6 +36,13 @@ ap.add_argument("--dock-ft-steps", type=float, default=3e8)
 ap.add_argument("--dock-zip", default="", help="skip Finisher training and use this checkpoint")
 ap.add_argument("--episodes", type=int, default=200)
 ap.add_argument("--handoff-mode", default="first_confirmed")
+ap.add_argument("--dock-envs", type=int, default=4096)
+ap.add_argument("--dock-n-steps", type=int, default=36)
+ap.add_argument("--dock-batch", type=int, default=0, help="minibatch rows; 0 = rollout/64")
+ap.add_argument("--dock-hidden", type=int, default=256)
+ap.add_argument("--dock-scratch-lr", type=float, default=1e-4)
+ap.add_argument("--dock-scratch-epochs", type=int, default=4)
+ap.add_argument("--dock-seed", type=int, default=7)
 args = ap.parse_args()
 
 cfg_a = kcfg.load_workspace_expansion_config(kcfg.builtin_config_dir() / f"{args.approach_config}.yaml")
@@ -58,19 +65,21 @@ dock = yaml.safe_load((kcfg.builtin_config_dir() / "dock_workspace_handoff_noop_
 dock["env"]["dock_reset"]["handoff_state_buffer_path"] = str(tmp / "finisher_handoff_state_buffer.json")
 (tmp / "dock_ft.yaml").write_text(yaml.safe_dump(dock))                      # the config's own algorithms.ppo: lr 3e-6, clip 0.08, 5 epochs
 scratch = json.loads(json.dumps(dock))
-scratch["algorithms"]["ppo"].update({"learning_rate": 1e-4, "ent_coef": 1e-4, "n_epochs": 4, "clip_range": 0.1})
+scratch["algorithms"]["ppo"].update({"learning_rate": args.dock_scratch_lr, "ent_coef": 1e-4, "n_epochs": args.dock_scratch_epochs, "clip_range": 0.1})
 (tmp / "dock_scratch.yaml").write_text(yaml.safe_dump(scratch))
 training = {}
+scale = ["--n-envs", str(args.dock_envs), "--n-steps", str(args.dock_n_steps), "--batch-size", str(args.dock_batch), "--hidden", str(args.dock_hidden),
+         "--seed", str(args.dock_seed), "--log-every", "100"]
 if args.dock_zip:
     dock_zip = args.dock_zip
 else:
     s1 = train_dock.main(["--config", str(tmp / "dock_scratch.yaml"), "--artifact-root", str(tmp / "dock_scratch"), "--total-timesteps", str(int(args.dock_steps)),
-                          "--n-envs", "4096", "--n-steps", "36", "--log-every", "100"])
+                          *scale])
     training["scratch"] = {k: s1[k] for k in ("num_timesteps", "wall_seconds", "env_steps_per_second", "dock_eval_summary")}
     dock_zip = s1["model_path"]
     if args.dock_ft_steps > 0:
         s2 = train_dock.main(["--config", str(tmp / "dock_ft.yaml"), "--artifact-root", str(tmp / "dock_ft"), "--total-timesteps", str(int(args.dock_ft_steps)),
-                              "--n-envs", "4096", "--n-steps", "36", "--log-every", "100", "--resume-from", dock_zip])
+                              *scale, "--resume-from", dock_zip])
         training["fine_tune"] = {k: s2[k] for k in ("num_timesteps", "wall_seconds", "env_steps_per_second", "dock_eval_summary")}
         dock_zip = s2["model_path"]
 finisher = InferencePolicy.load(dock_zip)
@@ -90,8 +99,9 @@ for name, fin, fcfg in (("approach_only", None, None), ("approach_plus_finisher"
             rows[name][k]["mean_approach_final_position_error"] = sum(r["approach_final_position_error"] for r in mine) / len(mine)
             rows[name][k]["mean_approach_final_orientation_error"] = sum(r["approach_final_orientation_error"] for r in mine) / len(mine)
     print(name, json.dumps(rows[name]), flush=True)
-out = {"approach_checkpoint": args.approach_zip, "approach_config": args.approach_config, "handoff_mode": args.handoff_mode, "handoff_states": len(states),
-       "handoff_buffer": buffer_stats, "dock_training": training, "evaluation": rows,
+out = {"command": "python " + " ".join(sys.argv), "approach_checkpoint": args.approach_zip, "approach_config": args.approach_config, "handoff_mode": args.handoff_mode, "handoff_states": len(states),
+       "handoff_buffer": buffer_stats, "dock_scale": {"n_envs": args.dock_envs, "n_steps": args.dock_n_steps, "batch": args.dock_batch, "hidden": args.dock_hidden},
+       "dock_training": training, "evaluation": rows,
        "target": {"stage5_success": 0.93, "stage5_final_position_error_m": 0.00289, "source": "report/OFFICIAL_ARTIFACTS.md:26"}}
 Path(args.out).parent.mkdir(parents=True, exist_ok=True)
 Path(args.out).write_text(json.dumps(out, indent=1))
