@@ -1153,10 +1153,19 @@ int launch_nt(const GemmNT& g, hipStream_t stream) {
 // dW (both nets) = D^T X over n rows: split-B partial tiles into m->slab, then the fixed-order reduce into G
 int launch_tn(kp1_mlp* m, GemmTN t, int n_o_tiles, int slab_cols, float* slab, int* n_chunks_out, hipStream_t stream);
 
-int launch_fused(const FusedArgs& fa, hipStream_t stream) {
-  using G = FuGeom<true>;   // 64-row tiles, 8 waves, one workgroup per CU
-  const size_t bytes = sizeof(float) * G::LDS_FLOATS;
+int launch_fused(const FusedArgs& fa_in, hipStream_t stream) {
+  using G = FuGeom<true>;
+  FusedArgs fa = fa_in;
+  static const int stagger_us = [] { const char* e = std::getenv("KP1_FU_STAGGER_US"); return e ? std::atoi(e) : 12; }();  // tuning knob
+  static const int n_cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    return n;
+  }();
   const dim3 grid((fa.n + G::BM - 1) / G::BM, 1, 2);
+  fa.n_cus = n_cus;
+  fa.stagger_ticks = (G::RB == 1 && (int)(grid.x * grid.z) > n_cus) ? stagger_us * 100 : 0;   // only when CUs hold two workgroups at once
+  const size_t bytes = sizeof(float) * G::LDS_FLOATS;
   if (fa.inp == 64) {
     HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     hipLaunchKernelGGL((mlp_tile_kernel<true, 2>), grid, dim3(G::NTH), bytes, stream, fa);

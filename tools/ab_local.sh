@@ -1,6 +1,7 @@
 #!/bin/bash
 # developer A/B, two halves.  HERE (no GPU):  bash tools/ab_local.sh build NAME=-DFLAG[,-DFLAG2] ...   builds tools/build/variants/libkp1_NAME.so
-# (only kp1_mlp.hip is recompiled per variant).  On the GPU box:  bash tools/ab_local.sh run [NAME ...]  times the MLP kernels with each.
+# (only kp1_mlp.hip is recompiled per variant).  On the GPU box:  bash tools/ab_local.sh run|bench [NAME ...]  times the MLP kernels with each
+# (bench: also one bench.py run per variant, i.e. the kernels in situ).
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 V=$ROOT/tools/build/variants
@@ -26,6 +27,9 @@ else
     case "$name" in *@*) lib=${name%%@*}; env_kv=${name#*@};; esac
     cp $V/libkp1_$lib.so rl_brain_trainer_amd/libkp1.so
     echo "variant $name"; env $env_kv timeout -k 10 120 python tools/prof_mlp.py 8192 40 2>/dev/null | tail -1
+    if [ "$mode" = bench ]; then   # the kernels in situ: one bench run per variant (in-situ event timing of a whole update epoch)
+      env $env_kv timeout -k 10 300 python bench.py --no-extras --no-cpu-baseline > /tmp/ab_bench.json 2>/dev/null && python3 tools/bench_line.py /tmp/ab_bench.json
+    fi
   done
   cp /tmp/lib_keep.so rl_brain_trainer_amd/libkp1.so
 fi
