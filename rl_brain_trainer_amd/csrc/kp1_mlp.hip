@@ -1200,7 +1200,7 @@ int launch_tn_frag(const TnFragArgs& t, hipStream_t stream) {
   if (t.n_chunks2 > 64 || t.n_chunks1 > 64) return fail(KP1_ERR_INVALID, "too many batch chunks for the partial-gradient slabs");
   const size_t bytes = sizeof(float) * 128 * (128 + 4);
   HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_frag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  hipLaunchKernelGGL(gemm_tn_frag_kernel, dim3(8 * t.n_chunks2), dim3(TNF_THREADS), bytes, stream, t);
+  hipLaunchKernelGGL(gemm_tn_frag_kernel, dim3(8 * t.n_chunks2 + 4 * t.n_chunks1), dim3(256), bytes, stream, t);
   return KP1_OK;
 }
 
