@@ -57,6 +57,39 @@ __device__ unsigned long long kp1_nt_trace_buf[KP1_TRACE_SLOTS * KP1_TRACE_WGS];
 #define KP1_TR_HW(slot)
 #endif
 
+// Cache policy of the big once-written / once-read streams (build switches; the defaults are the measured optimum).
+// aux bits of the gfx950 buffer instructions: 1 = sc0, 2 = nt, 16 = sc1.  sc1 stores are write-through: the line leaves the XCD's L2 when it
+// is written instead of at the kernel's end-of-launch write-back, and the consumer (another launch, mostly on another XCD) reads it from
+// HBM / the memory-side cache either way.
+#ifndef KP1_FU_ST_AUX
+#define KP1_FU_ST_AUX 0    // tile kernel: X / h1 / dZ2 / dZ1 activation stores
+#endif
+#ifndef KP1_TNF_ST_AUX
+#define KP1_TNF_ST_AUX 16  // weight-gradient kernel: partial-slab stores (write-through: 30.4 -> 29.0 us in situ, profiles/r02_ab_cache_policy.log)
+#endif
+#ifndef KP1_TNF_LD_NT
+#define KP1_TNF_LD_NT 0    // weight-gradient kernel: activation operand loads non-temporal
+#endif
+#ifndef KP1_FIN_LD_NT
+#define KP1_FIN_LD_NT 0    // finalize kernel: partial-slab loads non-temporal
+#endif
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte store of `v` at float index `idx` of the (wave-uniform) base pointer with cache policy AUX; AUX = 0 is a plain global store
+template <int AUX>
+__device__ __forceinline__ void store16(float* __restrict__ base, int64_t idx, const f32x4 v) {
+  if constexpr (AUX == 0) {
+    *reinterpret_cast<f32x4*>(base + idx) = v;
+  } else {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)(idx * 4), 0, AUX);
+  }
+}
+template <int NT>
+__device__ __forceinline__ f32x4 load16(const float* __restrict__ p) {
+  if constexpr (NT == 0) return *reinterpret_cast<const f32x4*>(p);
+  else return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+}
+
 // tanh(x) = 2 / (1 + 2^(-2 log2(e) x)) - 1 in FIVE vector instructions (v_mul, v_exp_f32, v_add, v_rcp_f32, v_fma = 28 issue cycles).
 // Instruction count matters more here than anywhere else in the kernel: v_mfma_f32_32x32x2_f32 runs on the SIMD's fp32 FMA lanes, so
 // vector-ALU work never overlaps with fp32 MFMAs -- not inside a wave (one v_fma between two MFMAs costs its full 4 cycles on top of the
@@ -871,7 +904,7 @@ __host__ __device__ inline int64_t finalize_vec_items(const ParamLayout& L) { re
 
 __global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a, int n_main) {
   const ParamLayout& L = a.L;
-  __shared__ double sq[256];
+  __shared__ double sq[4];
   __shared__ float red[8][32];
   float gval = 0.f;
   double gsq = 0.0;
@@ -898,14 +931,23 @@ __global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a
       }
       f32x4 s = {0.f, 0.f, 0.f, 0.f};
       int c = 0;
+      // the kernel is bound by memory round trips, not bandwidth: 32 partials (one whole dW2 element at the default batch split) are in
+      // flight before the first add; the adds keep the chunk order 0, 1, 2, ... whatever the unroll
+      for (; c + 32 <= n; c += 32) {
+        f32x4 v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = load16<KP1_FIN_LD_NT>(src + (int64_t)(c + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s += v[u];
+      }
       for (; c + 16 <= n; c += 16) {
         f32x4 v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(c + u) * stride);
+        for (int u = 0; u < 16; ++u) v[u] = load16<KP1_FIN_LD_NT>(src + (int64_t)(c + u) * stride);
 #pragma unroll
         for (int u = 0; u < 16; ++u) s += v[u];
       }
-      for (; c < n; ++c) s += *reinterpret_cast<const f32x4*>(src + (int64_t)c * stride);
+      for (; c < n; ++c) s += load16<KP1_FIN_LD_NT>(src + (int64_t)c * stride);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         a.grad[dst + q] = s[q];
@@ -960,13 +1002,12 @@ __global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a
       }
     }
   }
-  sq[threadIdx.x] = gsq + (double)gval * (double)gval;
+  // block sum of squares: shuffles inside a wave, the four wave sums through LDS (fixed order) -- one barrier instead of nine
+  double w = gsq + (double)gval * (double)gval;
+  for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off);
+  if ((threadIdx.x & 63) == 0) sq[threadIdx.x >> 6] = w;
   __syncthreads();
-  for (int k = 128; k > 0; k >>= 1) {
-    if (threadIdx.x < k) sq[threadIdx.x] += sq[threadIdx.x + k];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) a.sumsq[blockIdx.x] = sq[0];
+  if (threadIdx.x == 0) a.sumsq[blockIdx.x] = ((sq[0] + sq[1]) + sq[2]) + sq[3];
 }
 
 __global__ void __launch_bounds__(256) sumsq_partials_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ partials) {
@@ -990,12 +1031,15 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float*
                                                    float bc1, float bc2_sqrt, const ParamLayout L, const Packed k, int zero_grad,
                                                    const int* __restrict__ step_counter, int host_step, const int* __restrict__ actor_extra) {
   __shared__ float scale_s;
+  // this thread's element: its four loads do not depend on the norm, so they go out first and share one memory round trip with the
+  // step count and the norm partials below (the kernel is a chain of round trips: it moves 2.6 MB)
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < n;
+  const int64_t il = live ? i : n - 1;
+  const float g_in = g[il], m_in = m[il], v_in = v[il], p_in = p[il];
+  const int extra = *actor_extra;
   float base_step = (float)host_step;
-  if (step_counter) {  // bias corrections from the device-resident step count
-    base_step = (float)*step_counter;
-    bc1 = 1.f - powf(0.9f, base_step);
-    bc2_sqrt = sqrtf(1.f - powf(0.999f, base_step));
-  }
+  if (step_counter) base_step = (float)*step_counter;
   double s = 0.0;
   if (threadIdx.x < 64) {
     for (int k = threadIdx.x; k < n_partials; k += 64) s += partials[k];
@@ -1005,24 +1049,26 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float*
     const float norm = (float)sqrt(s);
     scale_s = max_norm > 0.f ? fminf(max_norm / (norm + 1e-6f), 1.f) : 1.f;
   }
+  if (step_counter) {  // bias corrections from the device-resident step count
+    bc1 = 1.f - powf(0.9f, base_step);
+    bc2_sqrt = sqrtf(1.f - powf(0.999f, base_step));
+  }
   __syncthreads();
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  if (!live) return;
   // torch.optim.Adam keeps one step count per tensor: the actor tensors (policy_net.*, action_net.*) have taken *actor_extra
   // more steps than the rest when a teacher-anchor side loss updates them between rollouts (route/teacher_anchor.py:68-87)
-  const int extra = *actor_extra;
   if (extra != 0 && ((i >= L.p_w1 && i < L.v_w1) || (i >= L.a_w && i < L.c_w))) {
     const float st = base_step + (float)extra;
     bc1 = 1.f - powf(0.9f, st);
     bc2_sqrt = sqrtf(1.f - powf(0.999f, st));
   }
-  const float gi = g[i] * scale_s;
-  const float mi = 0.9f * m[i] + 0.1f * gi;
-  const float vi = 0.999f * v[i] + 0.001f * gi * gi;
+  const float gi = g_in * scale_s;
+  const float mi = 0.9f * m_in + 0.1f * gi;
+  const float vi = 0.999f * v_in + 0.001f * gi * gi;
   m[i] = mi;
   v[i] = vi;
   const float denom = sqrtf(vi) / bc2_sqrt + eps;
-  const float pn = p[i] - (lr / bc1) * (mi / denom);
+  const float pn = p_in - (lr / bc1) * (mi / denom);
   p[i] = pn;
   pack_one(i, pn, L, k);
   if (zero_grad) g[i] = 0.f;

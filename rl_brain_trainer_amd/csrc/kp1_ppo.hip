@@ -43,11 +43,56 @@ __global__ void __launch_bounds__(256) bootstrap_kernel(float* __restrict__ rewa
 
 // PointCurriculumCallback._on_step; callbacks.py:71-92.  One wave.  Each lane loads 64 consecutive done bytes (4 x 16 B)
 // and condenses them into a 64-bit done mask and a success mask, so 4096 envs cost one round of loads; a ballot skips
-// the common case where no episode ended (95 of 96 steps at Stage 5).  Finished episodes are then replayed strictly in
-// env order by lane 0 (the masks of lane k are fetched with a shuffle), which is what the reference's sequential scan does.
-__device__ __forceinline__ void curriculum_scan(kp1_curriculum_state* __restrict__ st, const uint8_t* __restrict__ dones, int n, int steps_per_call) {
+// the common case where no episode ended.  Finished episodes are then replayed strictly in env order by lane 0 (the masks
+// of lane k are fetched with a shuffle), which is what the reference's sequential scan does.
+//
+// [r2] The tracker's state lives in registers and its success ring in LDS for the whole launch (TrackerCtx): round 2's profile had this
+// one-wave kernel at 13.2 us per env step (3 % of the PPO iteration) because lane 0 replayed ~45 finished episodes per step with every
+// field of *st re-read from global memory after every ring store (the compiler must assume the ring aliases them) -- a chain of
+// dependent memory round trips -- and, below the last stage, re-summed the whole ring per episode.  The window sum is now carried along
+// (sum += new - overwritten: the same integer the reference's sum(window) gives), so an episode costs a few LDS / scalar instructions.
+struct TrackerCtx {
+  int stage, count, len, head, window, min_episodes, max_stage, n_events, sum;
+  double threshold;
+  long long timesteps;
+  bool ring_dirty;
+};
+
+__device__ __forceinline__ void tracker_load(const kp1_curriculum_state* __restrict__ st, int* __restrict__ ring, TrackerCtx& c) {
   const int lane = threadIdx.x;
-  if (lane == 0) st->num_timesteps += steps_per_call;
+  c.stage = st->stage_index; c.count = st->stage_episode_count; c.len = st->ring_len; c.head = st->ring_head;
+  c.window = st->window_episodes; c.min_episodes = st->min_episodes_per_stage; c.max_stage = st->max_stage_index; c.n_events = st->n_events;
+  c.threshold = st->success_rate_threshold; c.timesteps = st->num_timesteps;
+  c.ring_dirty = false;
+  // live entries: the len positions from head on (while the ring is filling head is 0; once full every entry is live)
+  int part = 0;
+  for (int k = lane; k < c.window; k += 64) {
+    const int v = st->ring[k];
+    ring[k] = v;
+    const int age = k >= c.head ? k - c.head : k - c.head + c.window;
+    if (age < c.len) part += v;
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  c.sum = part;
+  __syncthreads();
+}
+
+__device__ __forceinline__ void tracker_store(kp1_curriculum_state* __restrict__ st, const int* __restrict__ ring, const TrackerCtx& c) {
+  const int lane = threadIdx.x;
+  __syncthreads();
+  if (c.ring_dirty)
+    for (int k = lane; k < c.window; k += 64) st->ring[k] = ring[k];
+  if (lane == 0) {
+    st->stage_index = c.stage; st->stage_episode_count = c.count; st->ring_len = c.len; st->ring_head = c.head;
+    st->n_events = c.n_events; st->num_timesteps = c.timesteps;
+  }
+}
+
+// consume dones[0 .. n) in index order.  c is wave-uniform on entry and on exit (lane 0's values are broadcast at the end).
+__device__ __forceinline__ void curriculum_scan(kp1_curriculum_state* __restrict__ st, int* __restrict__ ring, TrackerCtx& c,
+                                                const uint8_t* __restrict__ dones, int n, int steps_per_call) {
+  const int lane = threadIdx.x;
+  c.timesteps += steps_per_call;
   for (int base = 0; base < n; base += 64 * 64) {
     const int first = base + lane * 64;
     unsigned long long dmask = 0ull, smask = 0ull;
@@ -80,13 +125,14 @@ __device__ __forceinline__ void curriculum_scan(kp1_curriculum_state* __restrict
         }
       }
     }
-    if (__ballot(dmask != 0ull) == 0ull) continue;
-    int stage = 0, count = 0, len = 0, head = 0, window = 1;
-    if (lane == 0) {
-      stage = st->stage_index; count = st->stage_episode_count; len = st->ring_len; head = st->ring_head;
-      window = st->window_episodes;
-    }
-    for (int src = 0; src < 64; ++src) {
+    unsigned long long busy = __ballot(dmask != 0ull);
+    if (busy == 0ull) continue;
+    c.ring_dirty = true;
+    int stage = c.stage, count = c.count, len = c.len, head = c.head, sum = c.sum, n_events = c.n_events;
+    const int window = c.window;
+    while (busy) {   // lanes that saw a finished episode, in lane (= env) order
+      const int src = __ffsll((long long)busy) - 1;
+      busy &= busy - 1;
       unsigned long long m = __shfl(dmask, src);
       const unsigned long long sm = __shfl(smask, src);
       if (lane != 0) continue;
@@ -96,57 +142,62 @@ __device__ __forceinline__ void curriculum_scan(kp1_curriculum_state* __restrict
         const int success = (int)((sm >> b) & 1ull);
         count += 1;
         if (len < window) {
-          st->ring[(head + len) % window] = success;
+          ring[head + len < window ? head + len : head + len - window] = success;
           len += 1;
+          sum += success;
         } else {
-          st->ring[head] = success;
-          head = (head + 1) % window;
+          sum += success - ring[head];
+          ring[head] = success;
+          head = head + 1 < window ? head + 1 : 0;
         }
-        if (stage >= st->max_stage_index) continue;
-        if (count < st->min_episodes_per_stage) continue;
+        if (stage >= c.max_stage) continue;
+        if (count < c.min_episodes) continue;
         if (len < window) continue;
-        int s = 0;
-        for (int k = 0; k < len; ++k) s += st->ring[k];
-        const double rate = (double)s / (double)len;
-        if (rate >= st->success_rate_threshold) {
-          if (st->n_events < KP1_CURRICULUM_MAX_HISTORY) {
-            kp1_curriculum_event& ev = st->events[st->n_events];
-            ev.total_timesteps = st->num_timesteps;
+        const double rate = (double)sum / (double)len;
+        if (rate >= c.threshold) {
+          if (n_events < KP1_CURRICULUM_MAX_HISTORY) {
+            kp1_curriculum_event& ev = st->events[n_events];
+            ev.total_timesteps = c.timesteps;
             ev.from_stage = stage;
             ev.to_stage = stage + 1;
             ev.trigger_success_rate = rate;
           }
-          st->n_events += 1;
+          n_events += 1;
           stage += 1;
           count = 0;
           len = 0;
           head = 0;
+          sum = 0;
         }
       }
     }
-    if (lane == 0) {
-      st->stage_index = stage;
-      st->stage_episode_count = count;
-      st->ring_len = len;
-      st->ring_head = head;
-    }
+    c.stage = __shfl(stage, 0); c.count = __shfl(count, 0); c.len = __shfl(len, 0); c.head = __shfl(head, 0);
+    c.sum = __shfl(sum, 0); c.n_events = __shfl(n_events, 0);
   }
 }
 
 __global__ void __launch_bounds__(64) curriculum_kernel(kp1_curriculum_state* __restrict__ st, const uint8_t* __restrict__ dones, int n,
                                                         int steps_per_call) {
-  curriculum_scan(st, dones, n, steps_per_call);
+  __shared__ int ring[KP1_CURRICULUM_MAX_WINDOW];
+  TrackerCtx c;
+  tracker_load(st, ring, c);
+  curriculum_scan(st, ring, c, dones, n, steps_per_call);
+  tracker_store(st, ring, c);
 }
 
 // Data-parallel rollouts exchange the done bytes once per CHUNK of env steps instead of once per step: `dones` is the all-gathered
 // [world][chunk_steps][n_local] block (rank-major, as all_gather_into_tensor lays it out).  The tracker replays it in the order the
 // reference callback would have seen a single VecEnv of world * n_local envs: step by step, and inside a step rank by rank = global
-// env id order (callbacks.py:78-91).  One wave; the state written by lane 0 at the end of a scan is read back by lane 0 in the next.
+// env id order (callbacks.py:78-91).  One wave; the state stays in registers / LDS across the whole chunk.
 __global__ void __launch_bounds__(64) curriculum_chunk_kernel(kp1_curriculum_state* __restrict__ st, const uint8_t* __restrict__ dones, int n_local,
                                                               int chunk_steps, int world, int steps_per_env_step) {
+  __shared__ int ring[KP1_CURRICULUM_MAX_WINDOW];
+  TrackerCtx c;
+  tracker_load(st, ring, c);
   for (int t = 0; t < chunk_steps; ++t)
     for (int r = 0; r < world; ++r)
-      curriculum_scan(st, dones + ((int64_t)r * chunk_steps + t) * n_local, n_local, r == 0 ? steps_per_env_step : 0);
+      curriculum_scan(st, ring, c, dones + ((int64_t)r * chunk_steps + t) * n_local, n_local, r == 0 ? steps_per_env_step : 0);
+  tracker_store(st, ring, c);
 }
 
 int check_device(int device) {

@@ -316,6 +316,23 @@ class PPO:
         if self.use_graphs:
             self.noise_all = torch.zeros((T, N, ACT_DIM), dtype=torch.float32, device=dev)
             self.perm = torch.zeros(T * N, dtype=torch.int64, device=dev)
+            # the minibatch permutations of the coming update are drawn on a side stream while the rollout graph runs (torch.randperm of
+            # T * N elements is a radix sort + nine merge passes = 0.16 ms; eight of them between the epoch graphs were 2.4 % of the iteration)
+            self._perms = torch.zeros((max(int(cfg.n_epochs), 1), T * N), dtype=torch.int64, device=dev)
+            self._perm_stream = torch.cuda.Stream(device=dev)
+            self._perms_event = None
+
+    def _prefetch_perms(self) -> None:
+        """Draw the coming update's n_epochs permutations on the side stream; call BEFORE enqueuing the rollout so they overlap with it."""
+        side = self._perm_stream
+        if self._perms.shape[0] != max(int(self.cfg.n_epochs), 1):   # a resumed checkpoint brought its own n_epochs
+            self._perms = torch.zeros((max(int(self.cfg.n_epochs), 1), self._perms.shape[1]), dtype=torch.int64, device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))   # the previous update's reads of _perms are done
+        with torch.cuda.stream(side):
+            for e in range(self._perms.shape[0]):
+                torch.randperm(self._perms.shape[1], device=self.device, generator=self.gen, out=self._perms[e])
+            self._perms_event = torch.cuda.Event()
+            self._perms_event.record(side)
 
     def invalidate_graphs(self) -> None:
         """Drop the captured hipGraphs: a capture freezes host-side scalars into kernel arguments (env stage / mode / config pointers; learning
@@ -471,6 +488,7 @@ class PPO:
             if self._rollout_graph is None or self._rollout_graph_key != key:
                 self._capture_rollout()
                 self._rollout_graph_key = key
+            self._prefetch_perms()
             self._rollout_graph.replay()
         for t in range(0 if not graph_rollout else T, T):
             if self._mlp is not None:
@@ -574,9 +592,16 @@ class PPO:
         self.n_train_calls += 1
         if self._mlp is not None:
             self.stats_dev.zero_()
+        prefetched = self.use_graphs and self._perms_event is not None and self._perms.shape[0] == cfg.n_epochs
+        if prefetched:
+            torch.cuda.current_stream(self.device).wait_event(self._perms_event)
+            self._perms_event = None
         for _epoch in range(cfg.n_epochs):
             if self.use_graphs:
-                torch.randperm(total, device=self.device, generator=self.gen, out=self.perm)
+                if prefetched:
+                    self.perm.copy_(self._perms[_epoch])     # the epoch graph reads the fixed address self.perm
+                else:
+                    torch.randperm(total, device=self.device, generator=self.gen, out=self.perm)
                 if self._epoch_graph is not None and self._epoch_graph_key != self._epoch_key():
                     self._epoch_graph = None     # a hyper-parameter baked into the captured kernel arguments changed: capture again
                 if self._epoch_graph is None:
