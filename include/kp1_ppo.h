@@ -39,6 +39,10 @@ int kp1_bootstrap_truncated(int32_t device, float* rewards, const float* termina
  * epoch instead of one per minibatch) turns them into (mean, 1/(std+1e-8)) for kp1_mlp_loss_grad's adv_stats_dev. */
 int kp1_adv_minibatch_sums(int32_t device, const float* advantages, const int64_t* idx, int64_t total, int64_t minibatch, double* out_sums,
                            void* stream);
+/* (sum, sum of squares, count) f64 [n_minibatches][3] (after the data-parallel all-reduce, if any) -> f32 [n_minibatches][2] =
+ * (mean, 1 / (std + 1e-8)) with torch's unbiased std, in ONE launch (the same arithmetic in f64 as the tensor expressions it replaces:
+ * thirteen elementwise launches per epoch inside the update graph). */
+int kp1_adv_minibatch_stats(int32_t device, const double* sums, int64_t n_minibatches, float* out_stats, void* stream);
 
 /* ---- device-resident PointCurriculumCallback (kinematic_phase1/training/callbacks.py:32-101) --------------------
  * The callback scans (done, info["success"]) in env order after every VecEnv step and may promote the stage for ALL

@@ -73,6 +73,9 @@ __device__ unsigned long long kp1_nt_trace_buf[KP1_TRACE_SLOTS * KP1_TRACE_WGS];
 #ifndef KP1_FIN_LD_NT
 #define KP1_FIN_LD_NT 0    // finalize kernel: partial-slab loads non-temporal
 #endif
+#ifndef KP1_FIN_SPLIT
+#define KP1_FIN_SPLIT 1    // finalize kernel: adjacent lanes that share one float4 item and split its batch chunks (1, 2 or 4)
+#endif
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // 16-byte store of `v` at float index `idx` of the (wave-uniform) base pointer with cache policy AUX; AUX = 0 is a plain global store
 template <int AUX>
@@ -901,6 +904,10 @@ __device__ __forceinline__ int64_t finalize_wide_index(const ParamLayout& L, int
 // LDS combines the 8 strands in a fixed order -- a single thread summing 256 tiles was the tail of this kernel (8 dependent load rounds).
 // Every block leaves the sum of squares of what it wrote in sumsq[blockIdx.x] for clip_grad_norm_.
 __host__ __device__ inline int64_t finalize_vec_items(const ParamLayout& L) { return 2 * ((int64_t)L.H * L.H / 4 + (int64_t)L.H * L.IN / 4); }
+// KP1_FIN_SPLIT adjacent lanes share one item: lane part p sums the chunks [p * ceil(n / SPLIT), ...) in order and the parts are added in
+// part order by shuffles -- a fixed order, so still bitwise reproducible; more workgroups pull on the 25 MB of slabs at once
+constexpr int FIN_SPLIT = KP1_FIN_SPLIT;
+static_assert(FIN_SPLIT == 1 || FIN_SPLIT == 2 || FIN_SPLIT == 4, "KP1_FIN_SPLIT must be 1, 2 or 4");
 
 __global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a, int n_main) {
   const ParamLayout& L = a.L;
@@ -909,7 +916,8 @@ __global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a
   float gval = 0.f;
   double gsq = 0.0;
   if ((int)blockIdx.x < n_main) {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) / FIN_SPLIT;
+    const int part = threadIdx.x % FIN_SPLIT;
     const int64_t per2 = (int64_t)L.H * L.H / 4, per1 = (int64_t)L.H * L.IN / 4;
     if (j < 2 * (per2 + per1)) {
       const float* src;
@@ -929,6 +937,11 @@ __global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a
         stride = a.s1_chunk; n = a.s1_n;
         dst = (net ? L.v_w1 : L.p_w1) + row * L.IN + 4 * c4;
       }
+      if (FIN_SPLIT > 1) {   // this lane's share of the chunks
+        const int per = (n + FIN_SPLIT - 1) / FIN_SPLIT, c0 = min(part * per, n);
+        src += (int64_t)c0 * stride;
+        n = min(per, n - c0);
+      }
       f32x4 s = {0.f, 0.f, 0.f, 0.f};
       int c = 0;
       // the kernel is bound by memory round trips, not bandwidth: 32 partials (one whole dW2 element at the default batch split) are in
@@ -947,11 +960,29 @@ __global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a
 #pragma unroll
         for (int u = 0; u < 16; ++u) s += v[u];
       }
-      for (; c < n; ++c) s += load16<KP1_FIN_LD_NT>(src + (int64_t)c * stride);
+      for (; c + 8 <= n; c += 8) {
+        f32x4 v[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        a.grad[dst + q] = s[q];
-        gsq += (double)s[q] * (double)s[q];
+        for (int u = 0; u < 8; ++u) v[u] = load16<KP1_FIN_LD_NT>(src + (int64_t)(c + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; c < n; ++c) s += load16<KP1_FIN_LD_NT>(src + (int64_t)c * stride);
+      if (FIN_SPLIT > 1) {   // parts added in part order: ((p0 + p1) + p2) + p3
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float t = __shfl(s[q], (threadIdx.x & 63) - part);
+#pragma unroll
+          for (int k = 1; k < FIN_SPLIT; ++k) t += __shfl(s[q], (threadIdx.x & 63) - part + k);
+          s[q] = t;
+        }
+      }
+      if (part == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          a.grad[dst + q] = s[q];
+          gsq += (double)s[q] * (double)s[q];
+        }
       }
     }
     if (a.step_counter && blockIdx.x == 0 && threadIdx.x == 0) *a.step_counter += 1;  // read by the adam kernel that follows
@@ -1138,9 +1169,17 @@ struct ProfScope {
 namespace {
 
 constexpr int N_PARTIALS = 128;
+#ifndef KP1_TN_FORM
+#define KP1_TN_FORM 1      // 0: gemm_tn_frag_kernel (128 x 128 tiles, 32 batch chunks), 1: gemm_tn_split_kernel (64 x 64 tiles, 8 chunks, waves split the rows; default: profiles/r02_ab_tn_wave_split.log)
+#endif
 #ifndef KP1_TN_SPLIT2
-#define KP1_TN_SPLIT2 32   // batch chunks of the dW2 / dW1 partial tiles (gemm_tn_frag_kernel)
+#if KP1_TN_FORM == 1
+#define KP1_TN_SPLIT2 8    // batch chunks of the dW2 / dW1 partial tiles
+#define KP1_TN_SPLIT1 16
+#else
+#define KP1_TN_SPLIT2 32
 #define KP1_TN_SPLIT1 64
+#endif
 #endif
 
 // rows of the batch each TN workgroup reduces: aim at ~256 workgroups (one per CU) for the H x H gradient
@@ -1244,6 +1283,14 @@ int launch_fused_infer(const FusedArgs& fa, hipStream_t stream) {
 
 int launch_tn_frag(const TnFragArgs& t, hipStream_t stream) {
   if (t.n_chunks2 > 64 || t.n_chunks1 > 64) return fail(KP1_ERR_INVALID, "too many batch chunks for the partial-gradient slabs");
+#if KP1_TN_FORM == 1
+  {
+    const size_t bytes = sizeof(float) * TN_SPLIT_LDS_FLOATS;
+    HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL(gemm_tn_split_kernel, dim3(32 * t.n_chunks2 + 16 * t.n_chunks1), dim3(256), bytes, stream, t);
+    return KP1_OK;
+  }
+#endif
   const size_t bytes = sizeof(float) * 128 * (128 + 4);
   HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_frag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   hipLaunchKernelGGL(gemm_tn_frag_kernel, dim3(8 * t.n_chunks2 + 4 * t.n_chunks1), dim3(256), bytes, stream, t);
@@ -1538,8 +1585,8 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
     t.slab1 = m->slab1; t.s1_net = (int64_t)Hp * INP; t.s1_chunk = 2 * t.s1_net;
     t.groups = (n + FU_BM_TRAIN - 1) / FU_BM_TRAIN * (FU_BM_TRAIN / 8);   // the tile kernel writes whole 64-row tiles
     auto up8 = [](int v) { return (v + 7) / 8 * 8; };
-    t.cg2 = up8((t.groups + KP1_TN_SPLIT2 - 1) / KP1_TN_SPLIT2);   // ~32 chunks x 8 tiles = one dW2 workgroup per CU
-    t.cg1 = up8((t.groups + KP1_TN_SPLIT1 - 1) / KP1_TN_SPLIT1);   // ~64 chunks x 4 tiles of quarter-size dW1 workgroups
+    t.cg2 = up8((t.groups + KP1_TN_SPLIT2 - 1) / KP1_TN_SPLIT2);   // form 0: ~32 chunks x 8 tiles, form 1: 8 chunks x 32 tiles = one dW2 workgroup per CU
+    t.cg1 = up8((t.groups + KP1_TN_SPLIT1 - 1) / KP1_TN_SPLIT1);   // form 0: ~64 chunks x 4 tiles, form 1: 16 chunks x 16 tiles of quarter-size dW1 workgroups
     t.n_chunks2 = (t.groups + t.cg2 - 1) / t.cg2;
     t.n_chunks1 = (t.groups + t.cg1 - 1) / t.cg1;
     {
@@ -1576,7 +1623,7 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   f.ent_coef = ent_coef; f.inv_count = inv_count; f.log_std = m->k.log_std;
   f.grad = grad_out; f.stats = stats_out; f.sumsq = m->partials + 2 * N_PARTIALS;
   f.step_counter = m->step_dev;
-  const int n_main = (int)((finalize_vec_items(L) + 255) / 256);
+  const int n_main = (int)((finalize_vec_items(L) * FIN_SPLIT + 255) / 256);
   m->n_finalize_blocks = n_main + (int)((finalize_wide_count(L) + 3 + 31) / 32);
   if (m->n_finalize_blocks > 2048) return fail(KP1_ERR_INVALID, "parameter vector too large for the sum-of-squares partial buffer");
   {

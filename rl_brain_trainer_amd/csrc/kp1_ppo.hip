@@ -255,9 +255,32 @@ __global__ void __launch_bounds__(256) adv_minibatch_sums_kernel(const float* __
     out[3 * blockIdx.x + 2] = (double)(end - begin);
   }
 }
+// (sum, sum of squares, count) -> (mean, 1 / (unbiased std + 1e-8)); f64 arithmetic in the order of the torch expressions it replaces
+__global__ void __launch_bounds__(64) adv_minibatch_stats_kernel(const double* __restrict__ sums, int64_t n_mb, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= n_mb) return;
+  const double s0 = sums[3 * b], s1 = sums[3 * b + 1], cnt = sums[3 * b + 2];
+  const double mean = s0 / cnt;
+  const double dof = cnt - 1.0 < 1.0 ? 1.0 : cnt - 1.0;
+  double var = (s1 - cnt * mean * mean) / dof;
+  var = var < 0.0 ? 0.0 : var;
+  out[2 * b] = (float)mean;
+  out[2 * b + 1] = (float)(1.0 / (sqrt(var) + 1e-8));
+}
 }  // namespace
 
 extern "C" {
+
+int kp1_adv_minibatch_stats(int32_t device, const double* sums, int64_t n_minibatches, float* out_stats, void* stream) {
+  if (!sums || !out_stats || n_minibatches <= 0) return fail(KP1_ERR_INVALID, "bad argument to kp1_adv_minibatch_stats");
+  int rc = check_device(device);
+  if (rc != KP1_OK) return rc;
+  hipLaunchKernelGGL(adv_minibatch_stats_kernel, dim3((unsigned)((n_minibatches + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sums, n_minibatches,
+                     out_stats);
+  HIP_TRY(kp1::launch_status());
+  return KP1_OK;
+}
 
 int kp1_adv_minibatch_sums(int32_t device, const float* advantages, const int64_t* idx, int64_t total, int64_t minibatch, double* out_sums,
                            void* stream) {

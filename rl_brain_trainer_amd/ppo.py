@@ -649,10 +649,10 @@ class PPO:
         native.check(self.L.kp1_adv_minibatch_sums(self.device.index or 0, C.c_void_p(adv.data_ptr()), C.c_void_p(perm.data_ptr()), total, local_bs,
                                                    C.c_void_p(sums.data_ptr()), C.c_void_p(stream)))
         self.dist.all_reduce_sum(sums)
-        cnt = sums[:, 2]
-        mean = sums[:, 0] / cnt
-        var = ((sums[:, 1] - cnt * mean * mean) / (cnt - 1.0).clamp_min(1.0)).clamp_min(0.0)
-        return torch.stack([mean, 1.0 / (var.sqrt() + 1e-8)], dim=1).float().contiguous()
+        out = torch.empty((n_mb, 2), dtype=torch.float32, device=self.device)
+        native.check(self.L.kp1_adv_minibatch_stats(self.device.index or 0, C.c_void_p(sums.data_ptr()), n_mb, C.c_void_p(out.data_ptr()),
+                                                    C.c_void_p(stream)))
+        return out
 
     def _hip_minibatch_step(self, obs, idx, act, old_logp, adv, ret, device_step: bool = False, adv_stats=None) -> None:
         """one optimiser step, all on the device: gathered fwd + loss + bwd (MFMA), flat grad all-reduce, clip + Adam + repack"""

@@ -273,6 +273,20 @@ def test_adv_minibatch_sums_vs_torch():
         assert out[b, 2].item() == sel.numel()
         assert abs(out[b, 0].item() - sel.sum().item()) <= 1e-9 * sel.abs().sum().item()
         assert abs(out[b, 1].item() - (sel * sel).sum().item()) <= 1e-9 * (sel * sel).sum().item()
+    # (sum, sum^2, count) -> (mean, 1 / (std + 1e-8)): one launch against SB3's tensor expression (torch.std is unbiased)
+    stats = torch.zeros((n_mb, 2), dtype=torch.float32, device=DEV)
+    native.check(L.kp1_adv_minibatch_stats(0, C.c_void_p(out.data_ptr()), n_mb, C.c_void_p(stats.data_ptr()),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    for b in range(n_mb):
+        sel = adv[perm[b * mb:(b + 1) * mb]]
+        assert abs(stats[b, 0].item() - sel.mean().item()) <= 1e-6
+        assert abs(stats[b, 1].item() - 1.0 / (sel.std().item() + 1e-8)) <= 1e-5 * stats[b, 1].item()
+    # a one-sample minibatch: variance 0 -> 1 / 1e-8, as (x - mean) / (0 + 1e-8) needs
+    one = torch.tensor([[2.5, 6.25, 1.0]], dtype=torch.float64, device=DEV)
+    st1 = torch.zeros((1, 2), dtype=torch.float32, device=DEV)
+    native.check(L.kp1_adv_minibatch_stats(0, C.c_void_p(one.data_ptr()), 1, C.c_void_p(st1.data_ptr()),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert st1[0, 0].item() == 2.5 and st1[0, 1].item() == pytest.approx(1e8, rel=1e-6)
 
 
 def test_compacted_truncation_bootstrap_matches_dense_path():
