@@ -63,7 +63,7 @@ class MlpKernels:
         native.check(self.L.kp1_mlp_set_option(self._h, self.OPT_STEP_COUNT, int(steps)))
 
     OPT_PROFILE = 4
-    PROFILE_SLOTS = ("mlp_train_tile", "gemm_tn_frag", "grad_finalize", "adam")
+    PROFILE_SLOTS = ("mlp_train_tile", "gemm_tn_split", "grad_finalize", "adam")
 
     def set_profile(self, on: bool) -> None:
         """HIP-event pairs around every launch of the optimiser step (eager launches only); read with ``profile_read``."""
@@ -118,6 +118,6 @@ class MlpKernels:
         ms = (C.c_float * 6)()
         fl = (C.c_double * 6)()
         native.check(self.L.kp1_mlp_time_kernels(self._h, _p(obs), obs.shape[-1], n, iters, C.cast(ms, C.c_void_p), C.cast(fl, C.c_void_p), self._stream()))
-        names = ("gemm_nt_fwd_l2", "gemm_nt_bwd_dz1", "gemm_tn_dw2", "gemm_nt_fwd_l1", "mlp_train_tile", "gemm_tn_frag")
+        names = ("gemm_nt_fwd_l2", "gemm_nt_bwd_dz1", "gemm_tn_dw2", "gemm_nt_fwd_l1", "mlp_train_tile", "gemm_tn_split")
         return {nm: {"ms": float(ms[i]), "flops": float(fl[i]), "tflops": float(fl[i]) / (float(ms[i]) * 1e-3) / 1e12}
                 for i, nm in enumerate(names) if ms[i] > 0}

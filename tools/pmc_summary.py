@@ -20,6 +20,7 @@ import sys
 
 SHORT = {
     "gemm_tn_frag_kernel": "gemm_tn_frag",
+    "gemm_tn_split_kernel": "gemm_tn_split",
     "grad_finalize_kernel": "grad_finalize",
     "adam_kernel": "adam",
     "kp1_step_kernel": "kp1_step",
