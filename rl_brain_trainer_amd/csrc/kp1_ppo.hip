@@ -255,6 +255,25 @@ __global__ void __launch_bounds__(256) adv_minibatch_sums_kernel(const float* __
     out[3 * blockIdx.x + 2] = (double)(end - begin);
   }
 }
+// keyed bijection on [0, 2^bits): every round is invertible modulo 2^bits (odd multiplier; x ^= x >> s with s >= 1), so the composition is
+// a permutation; multiplication carries low bits upward, the xorshift carries high bits downward.  Cycle walking restricts it to [0, n).
+struct PermKeys { uint32_t mul[4], add[4]; };
+__global__ void __launch_bounds__(256) permutation_kernel(int64_t* __restrict__ out, int64_t n, int bits, const PermKeys k) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t mask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+  const int sh = bits > 1 ? bits / 2 : 1;
+  uint32_t x = (uint32_t)i;
+  do {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      x = (x * k.mul[r] + k.add[r]) & mask;
+      x ^= x >> sh;
+    }
+  } while ((int64_t)x >= n);
+  out[i] = (int64_t)x;
+}
+
 // (sum, sum of squares, count) -> (mean, 1 / (unbiased std + 1e-8)); f64 arithmetic in the order of the torch expressions it replaces
 __global__ void __launch_bounds__(64) adv_minibatch_stats_kernel(const double* __restrict__ sums, int64_t n_mb, float* __restrict__ out) {
 #pragma clang fp contract(off)
@@ -271,6 +290,22 @@ __global__ void __launch_bounds__(64) adv_minibatch_stats_kernel(const double* _
 }  // namespace
 
 extern "C" {
+
+int kp1_random_permutation(int32_t device, int64_t n, const uint32_t* keys, int64_t* out, void* stream) {
+  if (!keys || !out || n <= 0 || n > ((int64_t)1 << 31)) return fail(KP1_ERR_INVALID, "bad argument to kp1_random_permutation");
+  int rc = check_device(device);
+  if (rc != KP1_OK) return rc;
+  int bits = 1;
+  while (((int64_t)1 << bits) < n) ++bits;
+  PermKeys k;
+  for (int r = 0; r < 4; ++r) {
+    k.mul[r] = keys[r] | 1u;     // odd: invertible modulo 2^bits
+    k.add[r] = keys[4 + r];
+  }
+  hipLaunchKernelGGL(permutation_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n, bits, k);
+  HIP_TRY(kp1::launch_status());
+  return KP1_OK;
+}
 
 int kp1_adv_minibatch_stats(int32_t device, const double* sums, int64_t n_minibatches, float* out_stats, void* stream) {
   if (!sums || !out_stats || n_minibatches <= 0) return fail(KP1_ERR_INVALID, "bad argument to kp1_adv_minibatch_stats");

@@ -89,6 +89,7 @@ def load() -> C.CDLL:
     L.kp1_bootstrap_truncated.argtypes = [i32, vp, vp, vp, f32, i64, vp]
     L.kp1_adv_minibatch_sums.argtypes = [i32, vp, vp, i64, i64, vp, vp]
     L.kp1_adv_minibatch_stats.argtypes = [i32, vp, i64, vp, vp]
+    L.kp1_random_permutation.argtypes = [i32, i64, vp, vp, vp]
     L.kp1_curriculum_create.argtypes = [i32, C.c_double, i32, i32, i32, i32, C.POINTER(vp)]
     L.kp1_curriculum_destroy.argtypes = [i32, vp]
     L.kp1_curriculum_observe.argtypes = [i32, vp, vp, i32, i32, vp]

@@ -23,10 +23,12 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import time
 from dataclasses import dataclass, field
 from typing import Any
 
+import numpy as np
 import torch
 
 from . import config as kcfg
@@ -277,6 +279,7 @@ class PPO:
         self.adv_buf = torch.zeros((T, N), dtype=torch.float32, device=dev)
         self.ret_buf = torch.zeros((T, N), dtype=torch.float32, device=dev)
         self.gen = torch.Generator(device=dev).manual_seed(int(cfg.seed) + 7919 * self.dist.rank)
+        self._perm_rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([int(cfg.seed), self.dist.rank, 0x6B7031])))   # shuffle keys
         self.num_timesteps = 0
         self._needs_reset = True
         self.last_stats: dict[str, float] = {}
@@ -316,23 +319,25 @@ class PPO:
         if self.use_graphs:
             self.noise_all = torch.zeros((T, N, ACT_DIM), dtype=torch.float32, device=dev)
             self.perm = torch.zeros(T * N, dtype=torch.int64, device=dev)
-            # the minibatch permutations of the coming update are drawn on a side stream while the rollout graph runs (torch.randperm of
-            # T * N elements is a radix sort + nine merge passes = 0.16 ms; eight of them between the epoch graphs were 2.4 % of the iteration)
-            self._perms = torch.zeros((max(int(cfg.n_epochs), 1), T * N), dtype=torch.int64, device=dev)
-            self._perm_stream = torch.cuda.Stream(device=dev)
-            self._perms_event = None
 
-    def _prefetch_perms(self) -> None:
-        """Draw the coming update's n_epochs permutations on the side stream; call BEFORE enqueuing the rollout so they overlap with it."""
-        side = self._perm_stream
-        if self._perms.shape[0] != max(int(self.cfg.n_epochs), 1):   # a resumed checkpoint brought its own n_epochs
-            self._perms = torch.zeros((max(int(self.cfg.n_epochs), 1), self._perms.shape[1]), dtype=torch.int64, device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))   # the previous update's reads of _perms are done
-        with torch.cuda.stream(side):
-            for e in range(self._perms.shape[0]):
-                torch.randperm(self._perms.shape[1], device=self.device, generator=self.gen, out=self._perms[e])
-            self._perms_event = torch.cuda.Event()
-            self._perms_event.record(side)
+    # Minibatch shuffles.  At the benchmarked size (524288 samples) a sort-based torch.randperm is 0.16 ms of full-chip kernels, eight times per
+    # iteration (2.5 %); drawing them on a side stream under the rollout only moved that time (the sort kernels fill the chip and the
+    # rollout's launches queue behind them: rollout +1.3 ms for update -1.7 ms).  From PERM_CIPHER_MIN samples on, the permutation is a keyed
+    # bijection evaluated per element (kp1_random_permutation: one elementwise launch); below it torch.randperm stays -- it is cheap there.
+    PERM_CIPHER_MIN = (1 << 17) if os.environ.get("KP1_PERM_CIPHER", "1") != "0" else (1 << 62)   # KP1_PERM_CIPHER=0: developer A/B switch
+
+    def _draw_perm(self, total: int, out: torch.Tensor | None = None) -> torch.Tensor:
+        """indices of one epoch's minibatches: a random permutation of [0, total) on the device (SB3: np.random.permutation in RolloutBuffer.get)"""
+        if self._mlp is None or total < self.PERM_CIPHER_MIN:
+            if out is None:
+                return torch.randperm(total, device=self.device, generator=self.gen)
+            return torch.randperm(total, device=self.device, generator=self.gen, out=out)
+        if out is None:
+            out = torch.empty(total, dtype=torch.int64, device=self.device)
+        keys = self._perm_rng.integers(0, 1 << 32, size=8, dtype=np.uint64).astype(np.uint32)
+        native.check(self.L.kp1_random_permutation(self.device.index or 0, total, keys.ctypes.data_as(C.c_void_p), C.c_void_p(out.data_ptr()),
+                                                   C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        return out
 
     def invalidate_graphs(self) -> None:
         """Drop the captured hipGraphs: a capture freezes host-side scalars into kernel arguments (env stage / mode / config pointers; learning
@@ -488,7 +493,6 @@ class PPO:
             if self._rollout_graph is None or self._rollout_graph_key != key:
                 self._capture_rollout()
                 self._rollout_graph_key = key
-            self._prefetch_perms()
             self._rollout_graph.replay()
         for t in range(0 if not graph_rollout else T, T):
             if self._mlp is not None:
@@ -592,16 +596,9 @@ class PPO:
         self.n_train_calls += 1
         if self._mlp is not None:
             self.stats_dev.zero_()
-        prefetched = self.use_graphs and self._perms_event is not None and self._perms.shape[0] == cfg.n_epochs
-        if prefetched:
-            torch.cuda.current_stream(self.device).wait_event(self._perms_event)
-            self._perms_event = None
         for _epoch in range(cfg.n_epochs):
             if self.use_graphs:
-                if prefetched:
-                    self.perm.copy_(self._perms[_epoch])     # the epoch graph reads the fixed address self.perm
-                else:
-                    torch.randperm(total, device=self.device, generator=self.gen, out=self.perm)
+                self._draw_perm(total, out=self.perm)     # the epoch graph reads the fixed address self.perm
                 if self._epoch_graph is not None and self._epoch_graph_key != self._epoch_key():
                     self._epoch_graph = None     # a hyper-parameter baked into the captured kernel arguments changed: capture again
                 if self._epoch_graph is None:
@@ -621,7 +618,7 @@ class PPO:
                 n_updates += (total + local_bs - 1) // local_bs
                 self.adam_t += (total + local_bs - 1) // local_bs
                 continue
-            perm = torch.randperm(total, device=self.device, generator=self.gen)
+            perm = self._draw_perm(total)
             mb_stats = self._epoch_adv_stats(adv, perm, total, local_bs) if self._mlp is not None else None
             for i, start in enumerate(range(0, total, local_bs)):
                 idx = perm[start:start + local_bs]

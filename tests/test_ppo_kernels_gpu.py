@@ -253,6 +253,44 @@ def test_device_curriculum_matches_golden_tracker():
         cur.close()
 
 
+def test_keyed_permutation_is_a_permutation_and_mixes():
+    """kp1_random_permutation (the minibatch shuffle above 2^17 samples): a bijection of [0, n) for any n (cycle walking below the next
+    power of two), different keys give different permutations, and consecutive outputs -- one minibatch is a run of them -- look like
+    uniform draws: occupancy of 64 equal bins by the first 8192 outputs within chi-square bounds, no lag-1 correlation."""
+    import ctypes as C
+
+    from rl_brain_trainer_amd import native
+
+    L = native.load()
+    rng = np.random.default_rng(5)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def draw(n, keys):
+        out = torch.empty(n, dtype=torch.int64, device=DEV)
+        k = np.asarray(keys, dtype=np.uint32)
+        native.check(L.kp1_random_permutation(0, n, k.ctypes.data_as(C.c_void_p), C.c_void_p(out.data_ptr()), stream))
+        return out
+
+    for n in (1, 2, 3, 5, 1000, 1 << 17, 524288, 524289, 1_000_003):
+        keys = rng.integers(0, 1 << 32, size=8, dtype=np.uint64)
+        p = draw(n, keys)
+        assert torch.equal(torch.sort(p).values, torch.arange(n, device=DEV)), n
+        if n >= 1000:
+            q = draw(n, rng.integers(0, 1 << 32, size=8, dtype=np.uint64))
+            assert (p == q).float().mean().item() < 0.01                      # another key, another permutation
+            assert (p == torch.arange(n, device=DEV)).float().mean().item() < 0.01
+    n = 524288
+    for trial in range(8):
+        p = draw(n, rng.integers(0, 1 << 32, size=8, dtype=np.uint64)).cpu().numpy()
+        head = p[:8192]
+        counts = np.bincount(head * 64 // n, minlength=64)
+        chi2 = ((counts - 128.0) ** 2 / 128.0).sum()                           # 63 degrees of freedom: mean 63, sd 11.2
+        assert chi2 < 63 + 6 * 11.3, (trial, chi2)
+        x = p.astype(np.float64) / n - 0.5
+        assert abs(np.mean(x[:-1] * x[1:]) * 12.0) < 0.01, trial               # lag-1 correlation of consecutive outputs
+        assert abs(np.mean(x * (np.arange(n) / n - 0.5)) * 12.0) < 0.01, trial  # and none with the input index
+
+
 def test_adv_minibatch_sums_vs_torch():
     """per-epoch advantage statistics: every minibatch's (sum, sum^2, count) in one launch, ragged last minibatch included"""
     import ctypes as C
