@@ -489,7 +489,7 @@ class PPO:
         graph_rollout = self.use_graphs and self.step_callback is None
         if graph_rollout:
             self.noise_all.normal_(generator=self.gen)
-            key = (getattr(env, "launch_args_version", 0), self.curriculum is not None)
+            key = (getattr(env, "launch_args_version", 0), self.curriculum is not None, cfg.gamma, cfg.gae_lambda)   # what a capture freezes
             if self._rollout_graph is None or self._rollout_graph_key != key:
                 self._capture_rollout()
                 self._rollout_graph_key = key
@@ -515,6 +515,15 @@ class PPO:
         if not graph_rollout:
             self._kernels_warm = True
         self.num_timesteps += T * N * world
+        if not graph_rollout:
+            self._post_rollout()     # (the captured rollout ends with it)
+
+    def _post_rollout(self) -> None:
+        """what SB3's collect_rollouts does after the last env step: time-limit bootstrap, value of the last observation, GAE.  Static shapes
+        and no host synchronisation, so the captured rollout graph carries it as its tail (a dozen small launches whose host latency
+        was 0.5 ms per iteration)."""
+        cfg = self.cfg
+        T, N = cfg.n_steps, self.n_envs
         self._bootstrap_truncated()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         dev = self.device.index or 0
@@ -553,6 +562,7 @@ class PPO:
                 self.env.step_into(self.clip_act, self.obs_buf[1], self.rew_buf[0], self.done_buf[0], self.term_obs_buf[0], True)
                 if self.curriculum is not None:
                     self.curriculum.observe(self.done_buf[0].zero_(), 0)   # also loads the module the chunk form of the tracker lives in
+                self._post_rollout()                                        # the graph's tail, once eagerly (its buffers are rewritten by the real rollout)
                 # the warm-up moved every env one step: start the episodes again (one extra reset() draw per env stream)
                 self.env.use_current_stream()
                 self.obs_buf[0].copy_(self.env.reset())
@@ -564,6 +574,7 @@ class PPO:
             self.env.use_current_stream()
             for t in range(T):
                 self._rollout_step_hip(t)
+            self._post_rollout()
         self.env.use_current_stream()
         self._rollout_graph = g
 
