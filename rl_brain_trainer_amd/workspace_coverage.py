@@ -429,19 +429,26 @@ def failure_reason(approach: dict[str, float], r, success: bool, dwell: bool) ->
 
 
 # --------------------------------------------------------------------------------------------- batched pair runner
-def run_pairs(*, pairs: list[dict[str, Any]], starts_by_id: dict[str, dict[str, Any]], targets_by_id: dict[str, dict[str, Any]], approach_policy,
-              approach_cfg: kcfg.EnvConfig, finisher_policy=None, finisher_cfg: kcfg.EnvConfig | None = None, handoff_confirm_steps: int = 2,
-              device: int = 0, obs_stride: int = 56, seed: int = 0) -> list[dict[str, Any]]:
-    """_run_pairs: every pair is one env of a vectorised Approach run (explicit initial state and goal), then the handed-off
-    ones continue in a vectorised Finisher run."""
+# per-pair results as one f64 row: 4 flags + 10 measurements (the columns every summary of this module is computed from)
+_COLS = ("success", "ready_hit", "ready_dwell", "coarse_dwell",
+         "a_final_position_error", "a_final_orientation_error", "a_final_action_magnitude", "a_final_dq_norm", "min_position_error", "min_orientation_error",
+         "final_position_error", "final_orientation_error", "final_action_magnitude", "final_dq_norm",
+         "approach_steps")   # env steps the Approach episode ran (throughput accounting; not part of the reference's episode rows)
+
+
+def _run_pairs_columns(*, pairs, starts_by_id, targets_by_id, approach_policy, approach_cfg, finisher_policy, finisher_cfg, handoff_confirm_steps: int,
+                       device: int, obs_stride: int, seed: int, first_env_id: int = 0):
+    """one vectorised Approach run over `pairs` (explicit initial state and goal per env), then the handed-off ones continue in a
+    vectorised Finisher run -> f64 [len(pairs), len(_COLS)] on the device.  Env k of this call is global env first_env_id + k."""
     import torch
 
     from . import evaluate as ev
     from .vec_env import ArmKinematicVecEnv
 
     E = len(pairs)
+    dev = torch.device("cuda", device)
     if E == 0:
-        return []
+        return torch.zeros((0, len(_COLS)), dtype=torch.float64, device=dev)
     nj = kcfg.NJ
     starts = [starts_by_id[p["start_id"]] for p in pairs]
     targets = [targets_by_id[p["target_id"]] for p in pairs]
@@ -454,7 +461,7 @@ def run_pairs(*, pairs: list[dict[str, Any]], starts_by_id: dict[str, dict[str, 
         "policy_mode": "approach",
     }
     r = approach_cfg.c.reward
-    env = ArmKinematicVecEnv(approach_cfg, E, device=device, seed=seed)
+    env = ArmKinematicVecEnv(approach_cfg, E, device=device, seed=seed, first_env_id=first_env_id)
     if obs_stride != 56:
         env.set_obs_stride(obs_stride)
     a_res, hand = ev.run_episodes(env, approach_policy, opts, ready_cfg=r, handoff_confirm_steps=handoff_confirm_steps)
@@ -464,10 +471,11 @@ def run_pairs(*, pairs: list[dict[str, Any]], starts_by_id: dict[str, dict[str, 
     src = {}
     for k in ("state_q", "state_dq", "state_prev_action", "state_goal_q", "state_goal_pose6"):
         src[k] = torch.where(final_ready[:, None], a_res[k], hand.get(k, torch.zeros_like(a_res[k])))
-    final = {k: a_res[k].clone() for k in ("final_position_error", "final_orientation_error", "final_action_magnitude", "final_dq_norm")}
+    finals = ("final_position_error", "final_orientation_error", "final_action_magnitude", "final_dq_norm")
+    final = {k: a_res[k].clone() for k in finals}
     success = a_res["success"].clone()
     if finisher_policy is not None and finisher_cfg is not None and bool(has_hand.any()):
-        fenv = ArmKinematicVecEnv(finisher_cfg, E, device=device, seed=seed)
+        fenv = ArmKinematicVecEnv(finisher_cfg, E, device=device, seed=seed, first_env_id=first_env_id)
         if obs_stride != 56:
             fenv.set_obs_stride(obs_stride)
         safe = {k: torch.where(has_hand[:, None], v, a_res[k]) for k, v in src.items()}
@@ -476,28 +484,65 @@ def run_pairs(*, pairs: list[dict[str, Any]], starts_by_id: dict[str, dict[str, 
         for k in final:
             final[k] = torch.where(has_hand, f_res[k], final[k])
         success = torch.where(has_hand, f_res["success"], success)
-    ready_hit = (a_res["ready_hit"] | final_ready).cpu().numpy()
-    ready_dwell = ((a_res["max_ready_streak"] >= handoff_confirm_steps) | final_ready).cpu().numpy()
-    coarse_dwell = (a_res["max_ready_streak"] >= handoff_confirm_steps).cpu().numpy()
-    A = {k: v.cpu().numpy() for k, v in a_res.items() if v.ndim == 1}
-    F = {k: v.cpu().numpy() for k, v in final.items()}
-    succ = success.cpu().numpy()
+    coarse_dwell = a_res["max_ready_streak"] >= handoff_confirm_steps
+    cols = [success, a_res["ready_hit"] | final_ready, coarse_dwell | final_ready, coarse_dwell,
+            *[a_res[k] for k in finals], a_res["min_position_error"], a_res["min_orientation_error"], *[final[k] for k in finals],
+            a_res["step_count"]]
+    return torch.stack([c.to(torch.float64) for c in cols], dim=1).contiguous()
+
+
+def _rows_from_columns(pairs: list[dict[str, Any]], cols: np.ndarray, r) -> list[dict[str, Any]]:
+    """the per-episode rows of eval_full_workspace_coverage.py:160-199 from the result columns"""
+    c = {name: cols[:, k] for k, name in enumerate(_COLS)}
     rows = []
     for idx, pair in enumerate(pairs):
-        approach = {k: float(A[k][idx]) for k in ("final_position_error", "final_orientation_error", "final_action_magnitude", "final_dq_norm")}
+        approach = {k: float(c["a_" + k][idx]) for k in ("final_position_error", "final_orientation_error", "final_action_magnitude", "final_dq_norm")}
+        succ = bool(c["success"][idx])
         rows.append({
             "episode_id": idx, "pair_id": pair["pair_id"], "start_id": pair["start_id"], "target_id": pair["target_id"],
             "start_source_type": pair.get("start_source_type"), "target_stage_id": pair.get("target_stage_id"), "target_bucket_id": pair.get("target_bucket_id"),
             "difficulty_class": pair.get("difficulty_class"), "joint_distance_l2": float(pair.get("joint_distance_l2", 0.0)),
-            "ee_position_distance": float(pair.get("ee_position_distance", 0.0)), "success": bool(succ[idx]),
-            "finisher_ready_hit": bool(ready_hit[idx]), "finisher_ready_dwell": bool(ready_dwell[idx]),
-            "failure_reason": failure_reason(approach, r, bool(succ[idx]), bool(coarse_dwell[idx])),
-            "final_position_error": float(F["final_position_error"][idx]), "final_orientation_error": float(F["final_orientation_error"][idx]),
+            "ee_position_distance": float(pair.get("ee_position_distance", 0.0)), "success": succ,
+            "finisher_ready_hit": bool(c["ready_hit"][idx]), "finisher_ready_dwell": bool(c["ready_dwell"][idx]),
+            "failure_reason": failure_reason(approach, r, succ, bool(c["coarse_dwell"][idx])),
+            "final_position_error": float(c["final_position_error"][idx]), "final_orientation_error": float(c["final_orientation_error"][idx]),
             "approach_final_position_error": approach["final_position_error"], "approach_final_orientation_error": approach["final_orientation_error"],
-            "min_position_error": float(A["min_position_error"][idx]), "min_orientation_error": float(A["min_orientation_error"][idx]),
-            "final_action_magnitude": float(F["final_action_magnitude"][idx]), "final_dq_norm": float(F["final_dq_norm"][idx]),
+            "min_position_error": float(c["min_position_error"][idx]), "min_orientation_error": float(c["min_orientation_error"][idx]),
+            "final_action_magnitude": float(c["final_action_magnitude"][idx]), "final_dq_norm": float(c["final_dq_norm"][idx]),
         })
     return rows
+
+
+def run_pairs(*, pairs: list[dict[str, Any]], starts_by_id: dict[str, dict[str, Any]], targets_by_id: dict[str, dict[str, Any]], approach_policy,
+              approach_cfg: kcfg.EnvConfig, finisher_policy=None, finisher_cfg: kcfg.EnvConfig | None = None, handoff_confirm_steps: int = 2,
+              device: int = 0, obs_stride: int = 56, seed: int = 0, dist=None) -> list[dict[str, Any]]:
+    """_run_pairs: every pair is one env of a vectorised Approach run, then the handed-off ones continue in a vectorised Finisher run.
+
+    Data parallel (``dist`` = ppo.Dist of an initialised process group; BASELINE configs[3]: 65536 envs = 8 x 8192): the pair list --
+    identical on every rank, it is a function of the seed -- is cut into contiguous rank blocks, each rank runs its block on its own GPU
+    (global env ids kept, so a pair's episode does not depend on the GPU count) and ONE all-gather of the f64 result columns gives every
+    rank the whole table; rows and summaries are then computed from it as in the single-process run."""
+    import torch
+
+    E = len(pairs)
+    if E == 0:
+        return []
+    common = dict(starts_by_id=starts_by_id, targets_by_id=targets_by_id, approach_policy=approach_policy, approach_cfg=approach_cfg,
+                  finisher_policy=finisher_policy, finisher_cfg=finisher_cfg, handoff_confirm_steps=handoff_confirm_steps, device=device,
+                  obs_stride=obs_stride, seed=seed)
+    if dist is not None and dist.enabled:
+        world, per = dist.world_size, (E + dist.world_size - 1) // dist.world_size
+        lo = min(dist.rank * per, E)
+        hi = min(lo + per, E)
+        mine = _run_pairs_columns(pairs=pairs[lo:hi], first_env_id=lo, **common)
+        block = torch.zeros((per, len(_COLS)), dtype=torch.float64, device=mine.device)
+        block[:hi - lo] = mine
+        table = torch.empty((world, per, len(_COLS)), dtype=torch.float64, device=mine.device)
+        dist.all_gather_into(table, block)
+        cols = table.view(world * per, len(_COLS))[:E]      # rank-major blocks = pair order
+    else:
+        cols = _run_pairs_columns(pairs=pairs, first_env_id=0, **common)
+    return _rows_from_columns(pairs, cols.cpu().numpy(), approach_cfg.c.reward)
 
 
 def _write_json(path: Path, payload: Any) -> None:
@@ -514,14 +559,16 @@ def evaluate_full_workspace_coverage(*, approach_policy, approach_cfg: kcfg.EnvC
                                      finisher_cfg: kcfg.EnvConfig | None = None, seed: int = 940001, episodes_per_split: int = 96,
                                      stage_samples_per_stage: int = 96, random_target_samples: int = 384, random_start_samples: int = 384,
                                      pair_count: int = 2048, handoff_confirm_steps: int = 2, include_home_stage_eval: bool = True, device: int = 0,
-                                     obs_stride: int = 56) -> dict[str, Any]:
+                                     obs_stride: int = 56, dist=None) -> dict[str, Any]:
     """evaluate_full_workspace_coverage with policies passed as callables (checkpoint loading is the caller's); same artefact
     files under ``artifact_root`` (maps/, *_random_start_eval_summary.json, workspace_bucket_metrics.json,
     full_workspace_coverage_summary.json, workspace_failure_report.json, home_start_stage_eval/)."""
     from . import evaluate as ev
 
     rng = np.random.default_rng(seed)
-    root = Path(artifact_root) if artifact_root is not None else None
+    # data parallel: maps, pairs and split selection are functions of the seed (identical on every rank); the episodes of each split are
+    # sharded over the ranks by run_pairs; rank 0 writes the artefacts
+    root = Path(artifact_root) if artifact_root is not None and (dist is None or dist.rank == 0) else None
     fk = _device_fk(device)
     target_samples, target_summary = generate_workspace_target_map(approach_cfg, seed=seed + 1, stage_samples_per_stage=stage_samples_per_stage,
                                                                    random_samples=random_target_samples, fk=fk)
@@ -543,7 +590,7 @@ def evaluate_full_workspace_coverage(*, approach_policy, approach_cfg: kcfg.EnvC
         selected = select_pairs(pairs, mode=split, limit=episodes_per_split, rng=rng)
         rows = run_pairs(pairs=selected, starts_by_id=starts_by_id, targets_by_id=targets_by_id, approach_policy=approach_policy, approach_cfg=approach_cfg,
                          finisher_policy=finisher_policy, finisher_cfg=finisher_cfg, handoff_confirm_steps=handoff_confirm_steps, device=device,
-                         obs_stride=obs_stride, seed=seed)
+                         obs_stride=obs_stride, seed=seed, dist=dist)
         split_rows[split] = rows
         if root is not None:
             _write_json(root / f"{split}_random_start_eval_summary.json", {"summary": summarize(rows), "episode_rows": rows})

@@ -142,3 +142,82 @@ def test_coverage_evaluator_end_to_end_matches_serial_oracle(tmp_path, gold):
         assert abs(row["approach_final_orientation_error"] - a_res["ori"]) <= 5e-4
         if a_res["max_streak"] >= 2:
             assert row["finisher_ready_dwell"] and row["finisher_ready_hit"]
+
+
+# --------------------------------------------------------------------------------------------- data parallel (BASELINE configs[3])
+def _servo_run(dist_ctx, out_path):
+    """the coverage evaluation with a servo policy (approach + finisher), optionally sharded over the ranks of `dist_ctx`"""
+    import torch
+
+    from rl_brain_trainer_amd import evaluate as ev
+
+    g = json.loads((GOLDEN / "coverage_maps.json").read_text())
+    acfg = load_golden_config(g["config"])
+    fcfg = load_golden_config("dock_workspace_handoff_noop_ft_12env_raw")
+    holder: dict = {}
+
+    def servo(obs):
+        env = holder["env"]
+        dl = torch.tensor(env.config.c.joints.delta_limit[:], device="cuda", dtype=torch.float64)
+        scale = env.config.c.env.dock_action_delta_scale or env.config.c.env.action_delta_scale
+        info = env.info()
+        return (0.9 * (info["goal_q"].double().t() - info["q"].double().t()) / (dl * scale)).clamp(-1, 1).to(env.dtype)
+
+    orig_run = ev.run_episodes
+
+    def run(env, policy, opts, **kw):
+        holder["env"] = env
+        return orig_run(env, policy, opts, **kw)
+
+    ev.run_episodes = run
+    try:
+        cov = wc.evaluate_full_workspace_coverage(approach_policy=servo, approach_cfg=acfg, finisher_policy=servo, finisher_cfg=fcfg, artifact_root=out_path,
+                                                  seed=g["seed"], episodes_per_split=37, stage_samples_per_stage=4, random_target_samples=12,
+                                                  random_start_samples=9, pair_count=160, include_home_stage_eval=False, dist=dist_ctx)
+    finally:
+        ev.run_episodes = orig_run
+    return cov
+
+
+def _coverage_rank(rank: int, world: int, port: int, out_dir: str) -> None:
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rl_brain_trainer_amd.ppo import Dist
+
+        cov = _servo_run(Dist(), os.path.join(out_dir, "dp"))
+        with open(os.path.join(out_dir, f"cov{rank}.json"), "w") as f:
+            json.dump(cov, f)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_coverage_evaluator_sharded_over_two_ranks_matches_single_process(tmp_path):
+    """BASELINE configs[3] shards the random-start evaluation over the GPUs of a node: the pair list is cut into rank blocks and ONE
+    all-gather of the f64 result columns gives every rank the whole table.  Two gloo ranks on one GPU (37 pairs per split: ragged
+    blocks of 19 + 18) must reproduce the single-process run exactly -- every episode row, every summary -- on both ranks, and only
+    rank 0 writes the artefact files."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    single = _servo_run(None, tmp_path / "single")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_coverage_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ranks = [json.loads((tmp_path / f"cov{r}.json").read_text()) for r in range(2)]
+    ref = json.loads(json.dumps(single))
+    assert ranks[0] == ref and ranks[1] == ref
+    for split in ("known", "frontier", "stress"):
+        a = json.loads((tmp_path / "single" / f"{split}_random_start_eval_summary.json").read_text())
+        b = json.loads((tmp_path / "dp" / f"{split}_random_start_eval_summary.json").read_text())
+        assert a == b and len(a["episode_rows"]) > 0
