@@ -8,4 +8,4 @@ for k in ("finisher", "config3_env_kernel", "minibatch512", "config4_eval_shard"
     if k in d:
         print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in d[k].items() if a not in ("workload", "note")})
 r = d["roofline"]
-print("roofline", round(r["frac"], 3), r["optimizer_step_kernels_us"], "rocprof", r.get("rocprof"))
+print("roofline", round(r["frac"], 3), r["optimizer_step_kernels_us"], "epochs", r.get("insitu_epochs_us"), "rocprof", r.get("rocprof"))
