@@ -49,6 +49,16 @@ def test_bench_gpus2_spawns_two_ranks():
         assert rec["roofline"]["frac"] > 0 and rec["roofline"]["optimizer_step_kernels_us"]["mlp_train_tile"] > 0
     assert "config3_env_kernel" in one and one["config3_env_kernel"]["envs"] == 32768 and one["config3_env_kernel"]["frac"] > 0
     assert one["minibatch512"]["optimizer_step_us_eager"] > 0
+    assert one["config4_eval_shard"]["pairs"] == 8192 and one["config4_eval_shard"]["env_steps"] >= 8192
+    assert [b["envs"] for b in one["config3_env_kernel"]["larger_batches"]] == [131072, 524288]
+
+
+def test_bench_gpus4_ranks_stay_in_sync():
+    """four ranks (gloo, one GPU): rank-count-dependent pieces -- shard offsets, the 1 / (world * n) loss scaling, ent_coef / world, the chunked
+    done exchange with four blocks per step -- leave all ranks with bit-identical parameters"""
+    four = _run_bench(4, {"KP1_BENCH_BACKEND": "gloo", "KP1_BENCH_SINGLE_DEVICE": "1"})
+    assert four["n_gpus"] == 4 and four["config"]["ranks_in_sync"] is True and four["config"]["parallelism"].startswith("dp4")
+    assert four["value"] > 0 and four["finisher"]["value"] > 0
 
 
 def test_chunked_done_exchange_matches_per_step_tracker():
