@@ -1057,23 +1057,42 @@ __global__ void __launch_bounds__(256) sumsq_partials_kernel(const float* __rest
 // torch.nn.utils.clip_grad_norm_ (coef = max_norm / (norm + 1e-6), clamped to 1) + torch.optim.Adam
 // The same pass repacks the updated element into the kernel-format weights and (zero_grad) clears the gradient, so the
 // next minibatch's atomic accumulation starts from zero without a memset launch.
-__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+// VEC = 4: a thread owns four consecutive elements (float4 loads / stores of p, g, m, v; the caller checks 16-byte alignment): a quarter of
+// the workgroups -- each of them sums the norm partials again -- and of the load instructions; per-element arithmetic unchanged.
+#ifndef KP1_ADAM_VEC
+#define KP1_ADAM_VEC 1     // 4 measured SLOWER (8.1 -> 12.9 us in situ, profiles/r02_ab_adam_vec4.log): the kernel is a latency chain per thread
+#endif                     // (scattered repack stores behind div / sqrt), so it wants more threads, not fatter ones
+#ifndef KP1_ADAM_BLOCK
+#define KP1_ADAM_BLOCK 256
+#endif
+template <int VEC>
+__global__ void __launch_bounds__(KP1_ADAM_BLOCK) adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, const double* __restrict__ partials, int n_partials, float lr, float eps, float max_norm,
                                                    float bc1, float bc2_sqrt, const ParamLayout L, const Packed k, int zero_grad,
                                                    const int* __restrict__ step_counter, int host_step, const int* __restrict__ actor_extra) {
   __shared__ float scale_s;
-  // this thread's element: its four loads do not depend on the norm, so they go out first and share one memory round trip with the
+  // this thread's elements: their loads do not depend on the norm, so they go out first and share one memory round trip with the
   // step count and the norm partials below (the kernel is a chain of round trips: it moves 2.6 MB)
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = i < n;
-  const int64_t il = live ? i : n - 1;
-  const float g_in = g[il], m_in = m[il], v_in = v[il], p_in = p[il];
+  const int64_t i0 = ((int64_t)blockIdx.x * KP1_ADAM_BLOCK + threadIdx.x) * VEC;
+  float g_in[VEC], m_in[VEC], v_in[VEC], p_in[VEC];
+  if (VEC == 4 && i0 + 3 < n) {
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i0), mv = *reinterpret_cast<const f32x4*>(m + i0);
+    const f32x4 vv = *reinterpret_cast<const f32x4*>(v + i0), pv = *reinterpret_cast<const f32x4*>(p + i0);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { g_in[j] = gv[j]; m_in[j] = mv[j]; v_in[j] = vv[j]; p_in[j] = pv[j]; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int64_t il = i0 + j < n ? i0 + j : n - 1;
+      g_in[j] = g[il]; m_in[j] = m[il]; v_in[j] = v[il]; p_in[j] = p[il];
+    }
+  }
   const int extra = *actor_extra;
   float base_step = (float)host_step;
   if (step_counter) base_step = (float)*step_counter;
   double s = 0.0;
   if (threadIdx.x < 64) {
-    for (int k = threadIdx.x; k < n_partials; k += 64) s += partials[k];
+    for (int q = threadIdx.x; q < n_partials; q += 64) s += partials[q];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
   }
   if (threadIdx.x == 0) {
@@ -1084,25 +1103,46 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float*
     bc1 = 1.f - powf(0.9f, base_step);
     bc2_sqrt = sqrtf(1.f - powf(0.999f, base_step));
   }
-  __syncthreads();
-  if (!live) return;
   // torch.optim.Adam keeps one step count per tensor: the actor tensors (policy_net.*, action_net.*) have taken *actor_extra
   // more steps than the rest when a teacher-anchor side loss updates them between rollouts (route/teacher_anchor.py:68-87)
-  if (extra != 0 && ((i >= L.p_w1 && i < L.v_w1) || (i >= L.a_w && i < L.c_w))) {
+  float bc1_a = bc1, bc2_sqrt_a = bc2_sqrt;
+  if (extra != 0) {
     const float st = base_step + (float)extra;
-    bc1 = 1.f - powf(0.9f, st);
-    bc2_sqrt = sqrtf(1.f - powf(0.999f, st));
+    bc1_a = 1.f - powf(0.9f, st);
+    bc2_sqrt_a = sqrtf(1.f - powf(0.999f, st));
   }
-  const float gi = g_in * scale_s;
-  const float mi = 0.9f * m_in + 0.1f * gi;
-  const float vi = 0.999f * v_in + 0.001f * gi * gi;
-  m[i] = mi;
-  v[i] = vi;
-  const float denom = sqrtf(vi) / bc2_sqrt + eps;
-  const float pn = p_in - (lr / bc1) * (mi / denom);
-  p[i] = pn;
-  pack_one(i, pn, L, k);
-  if (zero_grad) g[i] = 0.f;
+  __syncthreads();
+  const float scale = scale_s;
+  float pn[VEC], mn[VEC], vn[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const int64_t i = i0 + j;
+    const bool actor = extra != 0 && ((i >= L.p_w1 && i < L.v_w1) || (i >= L.a_w && i < L.c_w));
+    const float b1 = actor ? bc1_a : bc1, b2 = actor ? bc2_sqrt_a : bc2_sqrt;
+    const float gi = g_in[j] * scale;
+    mn[j] = 0.9f * m_in[j] + 0.1f * gi;
+    vn[j] = 0.999f * v_in[j] + 0.001f * gi * gi;
+    const float denom = sqrtf(vn[j]) / b2 + eps;
+    pn[j] = p_in[j] - (lr / b1) * (mn[j] / denom);
+  }
+  if (VEC == 4 && i0 + 3 < n) {
+    *reinterpret_cast<f32x4*>(m + i0) = f32x4{mn[0], mn[1], mn[2], mn[3]};
+    *reinterpret_cast<f32x4*>(v + i0) = f32x4{vn[0], vn[1], vn[2], vn[3]};
+    *reinterpret_cast<f32x4*>(p + i0) = f32x4{pn[0], pn[1], pn[2], pn[3]};
+    if (zero_grad) *reinterpret_cast<f32x4*>(g + i0) = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) pack_one(i0 + j, pn[j], L, k);
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int64_t i = i0 + j;
+      if (i < n) {
+        m[i] = mn[j]; v[i] = vn[j]; p[i] = pn[j];
+        pack_one(i, pn[j], L, k);
+        if (zero_grad) g[i] = 0.f;
+      }
+    }
+  }
 }
 
 #include "kp1_mlp_tile.inc"
@@ -1785,9 +1825,15 @@ int kp1_mlp_adam_step(kp1_mlp* m, float* params, float* grad, float* exp_avg, fl
   kfmt.formats = frag_only ? PACK_FRAG : (PACK_SLAB | PACK_FRAG);
   m->last_params = params;
   if (frag_only) m->slab_stale = true;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, params, grad, exp_avg, exp_avg_sq, n,
-                     norm_partials, n_norm_partials, lr, eps, max_grad_norm, bc1, std::sqrt(bc2), m->L, kfmt, zero_grad,
-                     step > 0 ? (const int*)nullptr : (const int*)m->step_dev, host_step, (const int*)m->step_dev + 1);
+  const bool vec4 = KP1_ADAM_VEC == 4 && ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+                                          reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;
+  const int* step_arg = step > 0 ? (const int*)nullptr : (const int*)m->step_dev;
+  if (vec4)
+    hipLaunchKernelGGL(adam_kernel<4>, dim3((unsigned)((n + 4 * KP1_ADAM_BLOCK - 1) / (4 * KP1_ADAM_BLOCK))), dim3(KP1_ADAM_BLOCK), 0, stream, params, grad, exp_avg, exp_avg_sq, n, norm_partials,
+                       n_norm_partials, lr, eps, max_grad_norm, bc1, std::sqrt(bc2), m->L, kfmt, zero_grad, step_arg, host_step, (const int*)m->step_dev + 1);
+  else
+    hipLaunchKernelGGL(adam_kernel<1>, dim3((unsigned)((n + KP1_ADAM_BLOCK - 1) / KP1_ADAM_BLOCK)), dim3(KP1_ADAM_BLOCK), 0, stream, params, grad, exp_avg, exp_avg_sq, n, norm_partials,
+                       n_norm_partials, lr, eps, max_grad_norm, bc1, std::sqrt(bc2), m->L, kfmt, zero_grad, step_arg, host_step, (const int*)m->step_dev + 1);
   HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }
