@@ -744,17 +744,20 @@ __host__ __device__ inline int64_t frag_at(int64_t n, int64_t k, int64_t N) {
 
 // flat SB3 vector element i -> its place(s) in the kernel-format weights (zero padding pre-set once at creation)
 __device__ __forceinline__ void pack_one(int64_t i, float v, const ParamLayout& L, const Packed& k) {
+  // 32-bit element offsets and unsigned divisions: a 64-bit signed division is a ~100-instruction software routine on this ISA and sat on the
+  // per-thread critical path of adam_kernel (the vector has < 2^31 elements)
   const int H = L.H, Hp = L.Hp, IN = L.IN, INP = L.INP;
+  const unsigned uH = (unsigned)H, uIN = (unsigned)IN;
   if (i < L.p_w1) {
     k.log_std[i] = v;
   } else if (i < L.p_b1) {
-    const int64_t e = i - L.p_w1;
-    if (k.formats & PACK_SLAB) k.w1p[slab_at(e / IN, e % IN, Hp)] = v;
-    if (k.formats & PACK_FRAG) k.w1f[frag_at(e / IN, e % IN, Hp)] = v;
+    const unsigned e = (unsigned)(i - L.p_w1), r = e / uIN, c = e - r * uIN;
+    if (k.formats & PACK_SLAB) k.w1p[slab_at(r, c, Hp)] = v;
+    if (k.formats & PACK_FRAG) k.w1f[frag_at(r, c, Hp)] = v;
   } else if (i < L.p_w2) {
     k.b1[i - L.p_b1] = v;
   } else if (i < L.p_b2) {
-    const int64_t e = i - L.p_w2, r = e / H, c = e % H;
+    const unsigned e = (unsigned)(i - L.p_w2), r = e / uH, c = e - r * uH;
     if (k.formats & PACK_SLAB) {
       k.w2[slab_at(r, c, Hp)] = v;
       k.w2t[slab_at(c, r, Hp)] = v;
@@ -766,13 +769,13 @@ __device__ __forceinline__ void pack_one(int64_t i, float v, const ParamLayout& 
   } else if (i < L.v_w1) {
     k.b2[i - L.p_b2] = v;
   } else if (i < L.v_b1) {
-    const int64_t e = i - L.v_w1;
-    if (k.formats & PACK_SLAB) k.w1p[(int64_t)Hp * INP + slab_at(e / IN, e % IN, Hp)] = v;
-    if (k.formats & PACK_FRAG) k.w1f[(int64_t)Hp * INP + frag_at(e / IN, e % IN, Hp)] = v;
+    const unsigned e = (unsigned)(i - L.v_w1), r = e / uIN, c = e - r * uIN;
+    if (k.formats & PACK_SLAB) k.w1p[(int64_t)Hp * INP + slab_at(r, c, Hp)] = v;
+    if (k.formats & PACK_FRAG) k.w1f[(int64_t)Hp * INP + frag_at(r, c, Hp)] = v;
   } else if (i < L.v_w2) {
     k.b1[Hp + i - L.v_b1] = v;
   } else if (i < L.v_b2) {
-    const int64_t e = i - L.v_w2, r = e / H, c = e % H;
+    const unsigned e = (unsigned)(i - L.v_w2), r = e / uH, c = e - r * uH;
     if (k.formats & PACK_SLAB) {
       k.w2[(int64_t)Hp * Hp + slab_at(r, c, Hp)] = v;
       k.w2t[(int64_t)Hp * Hp + slab_at(c, r, Hp)] = v;
@@ -784,8 +787,8 @@ __device__ __forceinline__ void pack_one(int64_t i, float v, const ParamLayout& 
   } else if (i < L.a_w) {
     k.b2[Hp + i - L.v_b2] = v;
   } else if (i < L.a_b) {
-    const int64_t e = i - L.a_w;
-    k.w3[(e / H) * Hp + e % H] = v;
+    const unsigned e = (unsigned)(i - L.a_w), r = e / uH;
+    k.w3[(int64_t)r * Hp + (e - r * uH)] = v;
   } else if (i < L.c_w) {
     k.b3[i - L.a_b] = v;
   } else if (i < L.c_b) {
@@ -916,7 +919,7 @@ __global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a
   float gval = 0.f;
   double gsq = 0.0;
   if ((int)blockIdx.x < n_main) {
-    const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) / FIN_SPLIT;
+    const int64_t j = (int64_t)((blockIdx.x * 256u + threadIdx.x) / (unsigned)FIN_SPLIT);
     const int part = threadIdx.x % FIN_SPLIT;
     const int64_t per2 = (int64_t)L.H * L.H / 4, per1 = (int64_t)L.H * L.IN / 4;
     if (j < 2 * (per2 + per1)) {
@@ -925,17 +928,17 @@ __global__ void __launch_bounds__(256) grad_finalize_kernel(const FinalizeArgs a
       int n;
       if (j < 2 * per2) {
         const int net = j >= per2;
-        const int64_t rem = j - net * per2, row = rem / (L.H / 4), c4 = rem % (L.H / 4);
-        src = a.slab2 + net * a.s2_net + row * a.s2_ld + 4 * c4;
+        const unsigned rem = (unsigned)(j - net * per2), q4 = (unsigned)(L.H / 4), row = rem / q4, c4 = rem - row * q4;   // 32-bit: see pack_one
+        src = a.slab2 + net * a.s2_net + (int64_t)row * a.s2_ld + 4 * c4;
         stride = a.s2_chunk; n = a.s2_n;
-        dst = (net ? L.v_w2 : L.p_w2) + row * L.H + 4 * c4;
+        dst = (net ? L.v_w2 : L.p_w2) + (int64_t)row * L.H + 4 * c4;
       } else {
         const int64_t k = j - 2 * per2;
         const int net = k >= per1;
-        const int64_t rem = k - net * per1, row = rem / (L.IN / 4), c4 = rem % (L.IN / 4);
-        src = a.slab1 + net * a.s1_net + row * a.s1_ld + 4 * c4;
+        const unsigned rem = (unsigned)(k - net * per1), q4 = (unsigned)(L.IN / 4), row = rem / q4, c4 = rem - row * q4;
+        src = a.slab1 + net * a.s1_net + (int64_t)row * a.s1_ld + 4 * c4;
         stride = a.s1_chunk; n = a.s1_n;
-        dst = (net ? L.v_w1 : L.p_w1) + row * L.IN + 4 * c4;
+        dst = (net ? L.v_w1 : L.p_w1) + (int64_t)row * L.IN + 4 * c4;
       }
       if (FIN_SPLIT > 1) {   // this lane's share of the chunks
         const int per = (n + FIN_SPLIT - 1) / FIN_SPLIT, c0 = min(part * per, n);
