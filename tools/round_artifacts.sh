@@ -11,7 +11,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 timeout -k 10 600 python -m pytest tests -q -m gpu > $out/gpu_tests.log 2>&1 && echo "gpu tests ok: $(tail -1 $out/gpu_tests.log)" || { echo "gpu tests FAILED"; tail -20 $out/gpu_tests.log; exit 1; }
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1 && echo "smoke ok: $(tail -1 $out/smoke.log | cut -c1-200)" || { echo "smoke FAILED"; tail -20 $out/smoke.log; exit 1; }
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline > $out/stats.log 2>&1 || { echo "rocprof stats FAILED"; tail -5 $out/stats.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 bench.py --no-extras --no-cpu-baseline > $out/stats.log 2>&1 || { echo "rocprof stats FAILED"; tail -5 $out/stats.log; exit 1; }
 cp "$(find $out/stats -name bench_kernel_stats.csv | sort | tail -1)" profiles/${tag}_bench_kernel_stats.csv && cp profiles/${tag}_bench_kernel_stats.csv $out/ && echo "stats ok"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/cfg3 -o env -- python3 tools/env_kernel_bench.py > $out/env_stats.log 2>&1 || { echo "env rocprof FAILED"; exit 1; }
 cp "$(find $out/cfg3 -name env_kernel_stats.csv | sort | tail -1)" $out/${tag}_config3_env_kernel_stats.csv && echo "config-3 env kernel stats ok"
