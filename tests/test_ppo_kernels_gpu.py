@@ -271,10 +271,30 @@ def test_keyed_permutation_is_a_permutation_and_mixes():
         native.check(L.kp1_random_permutation(0, n, k.ctypes.data_as(C.c_void_p), C.c_void_p(out.data_ptr()), stream))
         return out
 
+    def host_restatement(n, keys):
+        """the construction include/kp1_ppo.h documents: four rounds of (odd multiply + add, xorshift by bits // 2) modulo 2^bits, cycle-walked"""
+        bits = 1
+        while (1 << bits) < n:
+            bits += 1
+        mask, sh = np.uint64((1 << bits) - 1), np.uint64(bits // 2 if bits > 1 else 1)
+        mul = [np.uint64(int(k) | 1) for k in keys[:4]]
+        add = [np.uint64(int(k)) for k in keys[4:]]
+        out = np.empty(n, dtype=np.int64)
+        todo, cur = np.arange(n), np.arange(n, dtype=np.uint64)
+        while todo.size:
+            for r in range(4):
+                cur = ((cur * mul[r] + add[r]) & np.uint64(0xFFFFFFFF)) & mask
+                cur ^= cur >> sh
+            ok = cur < n
+            out[todo[ok]] = cur[ok].astype(np.int64)
+            todo, cur = todo[~ok], cur[~ok]
+        return out
+
     for n in (1, 2, 3, 5, 1000, 1 << 17, 524288, 524289, 1_000_003):
         keys = rng.integers(0, 1 << 32, size=8, dtype=np.uint64)
         p = draw(n, keys)
         assert torch.equal(torch.sort(p).values, torch.arange(n, device=DEV)), n
+        assert np.array_equal(p.cpu().numpy(), host_restatement(n, keys)), n
         if n >= 1000:
             q = draw(n, rng.integers(0, 1 << 32, size=8, dtype=np.uint64))
             assert (p == q).float().mean().item() < 0.01                      # another key, another permutation
