@@ -221,3 +221,35 @@ def test_coverage_evaluator_sharded_over_two_ranks_matches_single_process(tmp_pa
         a = json.loads((tmp_path / "single" / f"{split}_random_start_eval_summary.json").read_text())
         b = json.loads((tmp_path / "dp" / f"{split}_random_start_eval_summary.json").read_text())
         assert a == b and len(a["episode_rows"]) > 0
+
+
+@pytest.mark.gpu
+def test_config4_full_size_rank_shards_reproduce_the_unsharded_run():
+    """BASELINE configs[3] at its full size: 65536 random-start pairs of workspace_full_coverage_randomstart_overnight (160-step episodes),
+    pair list drawn as the reference's sampler draws it.  Size-independent property: the result columns of each of the eight 8192-pair rank
+    blocks (global env ids kept) are bit-identical to the corresponding rows of ONE 65536-env run -- what a pair's episode produces does not
+    depend on how the evaluation is cut over GPUs.  Deterministic elementwise policy of the observation (row-independent by construction)."""
+    import torch
+
+    from rl_brain_trainer_amd import config as kcfg
+
+    cfg = kcfg.to_env_config(kcfg.load_workspace_expansion_config(kcfg.builtin_config_dir() / "workspace_full_coverage_randomstart_overnight.yaml"))
+    fk = wc._device_fk(0)
+    targets, _ = wc.generate_workspace_target_map(cfg, seed=940002, stage_samples_per_stage=8, random_samples=64, fk=fk)
+    starts, _ = wc.generate_workspace_start_state_map(cfg, seed=940003, stage_samples_per_stage=4, random_samples=64, fk=fk)
+    n, shard = 65536, 8192
+    pairs, summary = wc.build_pair_sampler_summary(starts=starts, targets=targets, seed=940004, pair_count=n)
+    assert summary["pair_count"] == n and len(summary["difficulty_class_counts"]) >= 3
+
+    def policy(obs):
+        return torch.tanh(3.0 * obs[:, :7] - obs[:, 7:14] + 0.25 * obs[:, 14:21])
+
+    common = dict(starts_by_id={r["start_id"]: r for r in starts}, targets_by_id={r["target_id"]: r for r in targets}, approach_policy=policy,
+                  approach_cfg=cfg, finisher_policy=None, finisher_cfg=None, handoff_confirm_steps=2, device=0, obs_stride=56, seed=760001)
+    full = wc._run_pairs_columns(pairs=pairs, first_env_id=0, **common)
+    assert full.shape == (n, len(wc._COLS)) and torch.isfinite(full).all()
+    steps = full[:, wc._COLS.index("approach_steps")]
+    assert steps.min() >= 1 and steps.max() <= cfg.c.termination.max_episode_steps + 1
+    for r in range(n // shard):
+        part = wc._run_pairs_columns(pairs=pairs[r * shard:(r + 1) * shard], first_env_id=r * shard, **common)
+        assert torch.equal(part, full[r * shard:(r + 1) * shard]), r
