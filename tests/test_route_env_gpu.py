@@ -147,3 +147,44 @@ def test_route_env_f32_batch_matches_oracle_and_explicit_resets(route_q, prefix)
     env.reset()
     assert int(env.info()["route_index"].max()) <= 40
     env.close()
+
+
+def test_route_prefix170_rank_shards_reproduce_the_unsharded_batch(route_q):
+    """BASELINE configs[4] shards the route-curriculum envs over the GPUs of a node.  Size-independent property at a full shard size: 8192
+    route envs (170-waypoint prefix, sequence wrapper with per-waypoint hand-over and auto-reset) stepped as ONE batch give bit-identical
+    observations, rewards, done bytes and route indices to the same envs stepped as two rank blocks with their global env ids
+    (first_env_id = 0 / 4096) -- env i depends only on seed + i, whatever the cut."""
+    cfgd = _cfg_dict("route_curriculum_prefix170_routeobs_sequence2")
+    base = kcfg.to_env_config(cfgd)
+    rc = rcfg.route_config_from_dict(cfgd, max_route_index=170)
+    N, half, steps = 8192, 4096, 96
+    whole = RouteVecEnv(base, rc, route_q, N, seed=817)
+    parts = [RouteVecEnv(base, rc, route_q, half, seed=817, first_env_id=r * half) for r in range(2)]
+    obs = whole.reset()
+    obs_p = torch.cat([p.reset() for p in parts])
+    assert torch.equal(obs, obs_p)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dones = resets_past_120 = 0
+    for t in range(steps):
+        # noisy servo towards the current waypoint for most envs (so that hand-overs and route resets happen), pure noise for the rest
+        info = whole.info()
+        st = whole.get_state()
+        goal = torch.tensor(st["goal_q"], device="cuda", dtype=torch.float32)
+        q = torch.tensor(st["q"], device="cuda", dtype=torch.float32)
+        dl = torch.tensor(np.array(base.c.joints.delta_limit[:]) * base.c.env.action_delta_scale, device="cuda", dtype=torch.float32)
+        a = (0.8 * (goal - q) / dl + 0.05 * torch.randn((N, 7), device="cuda", generator=g)).clamp(-1, 1)
+        a[::5] = torch.rand((len(a[::5]), 7), device="cuda", generator=g) * 2 - 1
+        o, r, d = whole.step(a)
+        o, r, d = o.clone(), r.clone(), d.clone()
+        idx = whole.info()["route_index"].clone()
+        outs = [p.step(a[k * half:(k + 1) * half].contiguous()) for k, p in enumerate(parts)]
+        assert torch.equal(o, torch.cat([x[0] for x in outs])), t
+        assert torch.equal(r, torch.cat([x[1] for x in outs])), t
+        assert torch.equal(d, torch.cat([x[2] for x in outs])), t
+        assert torch.equal(idx, torch.cat([p.info()["route_index"] for p in parts])), t
+        dones += int(((d & 3) != 0).sum())
+        resets_past_120 += int((idx > 120).sum() > 0)
+    assert dones > N // 4 and resets_past_120 > 0      # episodes ended and were reset inside the launch; the window reaches past waypoint 120
+    whole.close()
+    for p in parts:
+        p.close()
