@@ -480,6 +480,31 @@ int kp1_step(kp1_env* env, const void* actions_dev, float* obs_dev, void* reward
 int kp1_observe(kp1_env* env, float* obs_dev);
 /* info dict as device SoA views valid until the next call on the handle */
 int kp1_get_info(kp1_env* env, kp1_info_view* view);
+
+/* ---- batched deterministic evaluator: the per-step bookkeeping of eval_workspace_expansion.py:86-211 (_run_policy /
+ * _run_approach_with_handoff) for all episodes of a vectorised run in ONE launch -------------------------------------------------
+ * Every episode is one env of `env` (no auto-reset).  After each kp1_step the caller hands over the norm of the action it applied and the
+ * done bytes; the kernel reads position / orientation error, executed |dq| and the env state from the handle and updates, for the episodes
+ * still alive: step count, sums and finals of |action| and |dq|, final and minimum errors, success, the state snapshot
+ * (q, dq, prev_action, goal_q, goal_pose6: what a handoff continues from), the finisher-ready hit / streak bookkeeping and -- the first
+ * time the streak reaches handoff_confirm_steps -- the first-confirmed handoff snapshot; then alive &= not done.  All buffers are device
+ * memory owned by the caller, layouts as noted (n = kp1_num_envs). */
+typedef struct kp1_eval_buffers {
+  double* metrics;        /* [8][n]: final pos err, final ori err, min pos err, min ori err, final |action|, final |dq|, sum |action|, sum |dq| */
+  int32_t* counters;      /* [4][n]: step_count, max_ready_streak, first_ready_step (-1 = never), current streak */
+  uint8_t* flags;         /* [4][n]: alive, success, ready_hit, handoff taken */
+  double* state;          /* [n][34]: q 7, dq 7, prev_action 7, goal_q 7, goal_pose6 6 of the last step the episode was alive */
+  double* hand_metrics;   /* [6][n]: pos, ori, |action|, |dq|, min pos, min ori at the handoff step (NULL when handoff_confirm_steps == 0) */
+  int32_t* hand_step;     /* [n] */
+  uint8_t* hand_success;  /* [n] */
+  double* hand_state;     /* [n][34] */
+  int32_t* n_alive;       /* [1]: episodes still alive after this call (lets the caller stop early without reading back [n] flags) */
+} kp1_eval_buffers;
+/* step == 0: initialise from the freshly reset env (finals = mins = current errors, everything else zero, alive = active[i] or 1 when
+ * active is NULL); step >= 1: account env step number `step`.  ready_thresholds = {pos, ori, |action|, |dq|} of the readiness predicate
+ * (reward config dock_coarse_ready_*; pos or ori <= 0 disables it, |action| / |dq| <= 0 skip that clause) or NULL for no ready tracking. */
+int kp1_eval_accumulate(kp1_env* env, const kp1_eval_buffers* buffers, const double* action_norm, const uint8_t* done, const uint8_t* active,
+                        int32_t step, const double* ready_thresholds, int32_t handoff_confirm_steps, void* stream);
 /* reward_components of the last step, device real[n_components][N]; names via kp1_component_name */
 int kp1_get_reward_components(kp1_env* env, const void** comps_dev, int32_t* n_components);
 int kp1_enable_reward_components(kp1_env* env, int32_t enable);

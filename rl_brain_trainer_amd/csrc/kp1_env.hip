@@ -912,6 +912,82 @@ int launch_reset(kp1_env* e, const uint8_t* mask, const ResetOptsDev& opts, int 
   return KP1_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- evaluator bookkeeping (kp1_eval_accumulate)
+// One lane per episode.  STATE_W = the 34 leading real fields of the handle (q, dq, prev_action, goal_q, goal_pose6: F_Q .. F_GOAL_POSE + 5).
+constexpr int EVAL_STATE_W = F_GOAL_POSE + 6;
+static_assert(EVAL_STATE_W == 34 && F_Q == 0, "kp1_eval_buffers::state is the leading 34 fields of the handle");
+template <typename R>
+__global__ void __launch_bounds__(256) eval_accumulate_kernel(const R* __restrict__ real, int n, kp1_eval_buffers b, const double* __restrict__ action_norm,
+                                                              const uint8_t* __restrict__ done, const uint8_t* __restrict__ active, int step, bool track_ready,
+                                                              double thr_pos, double thr_ori, double thr_act, double thr_dq, int confirm) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  int alive_after = 0;
+  if (i < n) {
+    double* M = b.metrics;
+    int32_t* C = b.counters;
+    uint8_t* F = b.flags;
+    const double pos = (double)real[(size_t)F_POS_ERR * n + i], ori = (double)real[(size_t)F_ORI_ERR * n + i];
+    if (step == 0) {
+      M[0 * (size_t)n + i] = pos; M[1 * (size_t)n + i] = ori; M[2 * (size_t)n + i] = pos; M[3 * (size_t)n + i] = ori;
+      for (int k = 4; k < 8; ++k) M[k * (size_t)n + i] = 0.0;
+      C[0 * (size_t)n + i] = 0; C[1 * (size_t)n + i] = 0; C[2 * (size_t)n + i] = -1; C[3 * (size_t)n + i] = 0;
+      const uint8_t a = active ? (active[i] ? 1 : 0) : 1;
+      F[0 * (size_t)n + i] = a; F[1 * (size_t)n + i] = 0; F[2 * (size_t)n + i] = 0; F[3 * (size_t)n + i] = 0;
+      for (int f = 0; f < EVAL_STATE_W; ++f) b.state[(size_t)i * EVAL_STATE_W + f] = (double)real[(size_t)f * n + i];
+      if (b.hand_metrics) {
+        for (int k = 0; k < 6; ++k) b.hand_metrics[k * (size_t)n + i] = 0.0;
+        b.hand_step[i] = 0;
+        b.hand_success[i] = 0;
+        for (int f = 0; f < EVAL_STATE_W; ++f) b.hand_state[(size_t)i * EVAL_STATE_W + f] = 0.0;
+      }
+      alive_after = a;
+    } else if (F[i]) {
+      const double an = action_norm[i], dqn = (double)real[(size_t)F_EXEC_DQ * n + i];
+      const uint8_t d = done[i];
+      const uint8_t succ = (d & KP1_DONE_SUCCESS) ? 1 : 0;
+      C[i] = step;
+      M[6 * (size_t)n + i] += an;
+      M[7 * (size_t)n + i] += dqn;
+      M[0 * (size_t)n + i] = pos; M[1 * (size_t)n + i] = ori; M[4 * (size_t)n + i] = an; M[5 * (size_t)n + i] = dqn;
+      const double mp = fmin(M[2 * (size_t)n + i], pos), mo = fmin(M[3 * (size_t)n + i], ori);
+      M[2 * (size_t)n + i] = mp; M[3 * (size_t)n + i] = mo;
+      F[1 * (size_t)n + i] = succ;
+      double st[EVAL_STATE_W];
+      for (int f = 0; f < EVAL_STATE_W; ++f) {
+        st[f] = (double)real[(size_t)f * n + i];
+        b.state[(size_t)i * EVAL_STATE_W + f] = st[f];
+      }
+      if (track_ready) {
+        bool rdy = thr_pos > 0.0 && thr_ori > 0.0 && pos <= thr_pos && ori <= thr_ori;
+        if (thr_act > 0.0) rdy = rdy && an <= thr_act;
+        if (thr_dq > 0.0) rdy = rdy && dqn <= thr_dq;
+        if (rdy) {
+          F[2 * (size_t)n + i] = 1;
+          if (C[2 * (size_t)n + i] < 0) C[2 * (size_t)n + i] = step;
+        }
+        const int streak = rdy ? C[3 * (size_t)n + i] + 1 : 0;
+        C[3 * (size_t)n + i] = streak;
+        if (streak > C[1 * (size_t)n + i]) C[1 * (size_t)n + i] = streak;
+        if (confirm > 0 && b.hand_metrics && !F[3 * (size_t)n + i] && streak >= confirm) {   // first-confirmed handoff snapshot
+          F[3 * (size_t)n + i] = 1;
+          double* H = b.hand_metrics;
+          H[0 * (size_t)n + i] = pos; H[1 * (size_t)n + i] = ori; H[2 * (size_t)n + i] = an; H[3 * (size_t)n + i] = dqn;
+          H[4 * (size_t)n + i] = mp; H[5 * (size_t)n + i] = mo;
+          b.hand_step[i] = step;
+          b.hand_success[i] = succ;
+          for (int f = 0; f < EVAL_STATE_W; ++f) b.hand_state[(size_t)i * EVAL_STATE_W + f] = st[f];
+        }
+      }
+      const uint8_t still = (d & (KP1_DONE_TERMINATED | KP1_DONE_TRUNCATED)) ? 0 : 1;
+      F[i] = still;
+      alive_after = still;
+    }
+  }
+  // episodes still alive: wave ballot, one atomic per wave (an integer count: order does not matter)
+  const unsigned long long bal = __ballot(alive_after != 0);
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(b.n_alive, __popcll(bal));
+}
+
 int ensure_scratch(kp1_env* e) {
   if (!e->opt_scratch) HIP_TRY(hipMalloc((void**)&e->opt_scratch, sizeof(double) * (size_t)e->n * (4 * NJ + 6)));
   return KP1_OK;
@@ -1150,6 +1226,28 @@ int kp1_get_info(kp1_env* e, kp1_info_view* v) {
   v->stage_index = e->ints + n * I_STAGE;
   v->n_envs = e->n;
   v->real_type = e->real_type;
+  return KP1_OK;
+}
+
+int kp1_eval_accumulate(kp1_env* e, const kp1_eval_buffers* b, const double* action_norm, const uint8_t* done, const uint8_t* active, int32_t step,
+                        const double* ready_thresholds, int32_t handoff_confirm_steps, void* stream) {
+  if (!e || !b || !b->metrics || !b->counters || !b->flags || !b->state || !b->n_alive) return fail(KP1_ERR_INVALID, "kp1_eval_accumulate: NULL buffer");
+  if (step < 0 || (step > 0 && (!action_norm || !done))) return fail(KP1_ERR_INVALID, "kp1_eval_accumulate: a step needs action norms and done bytes");
+  if (b->hand_metrics && (!b->hand_step || !b->hand_success || !b->hand_state)) return fail(KP1_ERR_INVALID, "kp1_eval_accumulate: incomplete handoff buffers");
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+  HIP_TRY(hipMemsetAsync(b->n_alive, 0, sizeof(int32_t), st));
+  const bool track = ready_thresholds != nullptr;
+  const double t0 = track ? ready_thresholds[0] : 0.0, t1 = track ? ready_thresholds[1] : 0.0, t2 = track ? ready_thresholds[2] : 0.0,
+               t3 = track ? ready_thresholds[3] : 0.0;
+  const dim3 grid((unsigned)((e->n + 255) / 256));
+  if (e->real_type == KP1_REAL_F64)
+    hipLaunchKernelGGL(eval_accumulate_kernel<double>, grid, dim3(256), 0, st, (const double*)e->real, e->n, *b, action_norm, done, active, step, track, t0, t1,
+                       t2, t3, handoff_confirm_steps);
+  else
+    hipLaunchKernelGGL(eval_accumulate_kernel<float>, grid, dim3(256), 0, st, (const float*)e->real, e->n, *b, action_norm, done, active, step, track, t0, t1, t2,
+                       t3, handoff_confirm_steps);
+  HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }
 

@@ -15,6 +15,7 @@ goal poses come from the fp64 HIP FK kernel.
 """
 from __future__ import annotations
 
+import ctypes as C
 import json
 from pathlib import Path
 from typing import Any, Callable
@@ -23,6 +24,7 @@ import numpy as np
 import torch
 
 from . import config as kcfg
+from . import native
 from .vec_env import ArmKinematicVecEnv, fk_pose6
 
 PolicyFn = Callable[[torch.Tensor], torch.Tensor]  # obs [E, stride] -> clipped deterministic action [E, 7]
@@ -188,9 +190,81 @@ def _snapshot(env: ArmKinematicVecEnv) -> dict[str, torch.Tensor]:
     return {k: info[k].t().clone().double() for k in ("q", "dq", "prev_action", "goal_q", "goal_pose6")}
 
 
+_STATE_SLICES = (("q", 0, 7), ("dq", 7, 14), ("prev_action", 14, 21), ("goal_q", 21, 28), ("goal_pose6", 28, 34))
+_ALIVE_CHECK_EVERY = 8      # env steps between two reads of the device's alive-episode counter
+
+
 def run_episodes(env: ArmKinematicVecEnv, policy: PolicyFn, reset_options: dict[str, Any], *, ready_cfg=None, handoff_confirm_steps: int = 0,
                  active: torch.Tensor | None = None, max_steps: int | None = None) -> tuple[dict[str, torch.Tensor], dict[str, torch.Tensor] | None]:
     """All episodes in lock step until each has terminated or truncated (_run_policy / _run_approach_with_handoff).
+
+    Returns (final_result, handoff_result): tensors over episodes.  handoff_result (if handoff_confirm_steps > 0) is the
+    snapshot at the first step where the ready streak reached handoff_confirm_steps, with ``valid`` marking who has one.
+
+    Per env step: the policy, the norm of its action, kp1_step, and ONE kp1_eval_accumulate launch that does the whole per-episode
+    bookkeeping on the device (finals / minima / sums, success, state snapshot, ready streak, first-confirmed handoff snapshot, alive
+    mask); the host looks at the alive-episode counter every _ALIVE_CHECK_EVERY steps.  Results are bit-identical to the tensor-expression
+    form (_run_episodes_reference; tests/test_eval_checkpoint_gpu.py)."""
+    E = env.n_envs
+    dev = env.device
+    L = native.load()
+    env.use_current_stream()
+    obs = env.reset(options=reset_options).clone()
+    f64, i32, u8 = torch.float64, torch.int32, torch.uint8
+    metrics = torch.empty((8, E), dtype=f64, device=dev)
+    counters = torch.empty((4, E), dtype=i32, device=dev)
+    flags = torch.empty((4, E), dtype=u8, device=dev)
+    state = torch.empty((E, 34), dtype=f64, device=dev)
+    n_alive = torch.zeros(1, dtype=i32, device=dev)
+    want_hand = handoff_confirm_steps > 0
+    hand_metrics = torch.empty((6, E), dtype=f64, device=dev) if want_hand else None
+    hand_step = torch.empty(E, dtype=i32, device=dev) if want_hand else None
+    hand_success = torch.empty(E, dtype=u8, device=dev) if want_hand else None
+    hand_state = torch.empty((E, 34), dtype=f64, device=dev) if want_hand else None
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    bufs = native.EvalBuffers(ptr(metrics), ptr(counters), ptr(flags), ptr(state), ptr(hand_metrics), ptr(hand_step), ptr(hand_success), ptr(hand_state),
+                              ptr(n_alive))
+    thr = None
+    if ready_cfg is not None:
+        thr = (C.c_double * 4)(ready_cfg.dock_coarse_ready_pos_threshold_m, ready_cfg.dock_coarse_ready_ori_threshold_rad,
+                               ready_cfg.dock_coarse_ready_action_threshold, ready_cfg.dock_coarse_ready_dq_threshold)
+    act_mask = None if active is None else active.to(dev).to(u8).contiguous()
+    native.check(L.kp1_eval_accumulate(env._handle, C.byref(bufs), None, None, ptr(act_mask), 0, thr, int(handoff_confirm_steps), None))
+    limit = int(max_steps or (env.config.c.termination.max_episode_steps + 1))
+    for step in range(1, limit + 1):
+        if (step - 1) % _ALIVE_CHECK_EVERY == 0 and int(n_alive.item()) == 0:
+            break
+        action = policy(obs)
+        a_norm = torch.linalg.vector_norm(action.double(), dim=1).contiguous()
+        obs, _, done = env.step(action, auto_reset=False)
+        obs = obs.clone()
+        native.check(L.kp1_eval_accumulate(env._handle, C.byref(bufs), ptr(a_norm), ptr(done), None, step, thr, int(handoff_confirm_steps), None))
+    res = {
+        "success": flags[1].bool(), "final_position_error": metrics[0], "final_orientation_error": metrics[1], "min_position_error": metrics[2],
+        "min_orientation_error": metrics[3], "final_action_magnitude": metrics[4], "final_dq_norm": metrics[5], "sum_action": metrics[6],
+        "sum_dq": metrics[7], "ready_hit": flags[2].bool(), "max_ready_streak": counters[1], "first_ready_step": counters[2], "step_count": counters[0],
+    }
+    steps = res["step_count"].clamp_min(1).double()
+    res["mean_action_magnitude"] = res["sum_action"] / steps
+    res["mean_dq_norm"] = res["sum_dq"] / steps
+    for k, lo, hi in _STATE_SLICES:
+        res["state_" + k] = state[:, lo:hi].contiguous()
+    hand = None
+    if want_hand:
+        hand = {"valid": flags[3].bool(), "final_position_error": hand_metrics[0], "final_orientation_error": hand_metrics[1],
+                "final_action_magnitude": hand_metrics[2], "final_dq_norm": hand_metrics[3], "min_position_error": hand_metrics[4],
+                "min_orientation_error": hand_metrics[5], "step_count": hand_step, "success": hand_success.bool()}
+        for k, lo, hi in _STATE_SLICES:
+            hand["state_" + k] = hand_state[:, lo:hi].contiguous()
+    return res, hand
+
+
+def _run_episodes_reference(env: ArmKinematicVecEnv, policy: PolicyFn, reset_options: dict[str, Any], *, ready_cfg=None, handoff_confirm_steps: int = 0,
+                 active: torch.Tensor | None = None, max_steps: int | None = None) -> tuple[dict[str, torch.Tensor], dict[str, torch.Tensor] | None]:
+    """The per-step bookkeeping as tensor expressions (about 45 launches and two host synchronisations per env step): the form
+    run_episodes had before kp1_eval_accumulate, kept as the test reference the device kernel is compared with bit for bit.
+
+    All episodes in lock step until each has terminated or truncated (_run_policy / _run_approach_with_handoff).
 
     Returns (final_result, handoff_result): tensors over episodes.  handoff_result (if handoff_confirm_steps > 0) is the
     snapshot at the first step where the ready streak reached handoff_confirm_steps, with ``valid`` marking who has one."""

@@ -21,6 +21,11 @@ DONE_TERMINATED, DONE_TRUNCATED, DONE_SUCCESS, DONE_INVALID = 1, 2, 4, 8
 FLAG_PRE_NEAR_HIT, FLAG_NEAR_HIT, FLAG_SUCCESS = 1, 2, 4
 
 
+class EvalBuffers(C.Structure):
+    """include/kp1.h kp1_eval_buffers: device pointers of the batched evaluator's per-episode accumulators"""
+    _fields_ = [(n, C.c_void_p) for n in ("metrics", "counters", "flags", "state", "hand_metrics", "hand_step", "hand_success", "hand_state", "n_alive")]
+
+
 class Kp1Error(RuntimeError):
     pass
 
@@ -71,6 +76,7 @@ def load() -> C.CDLL:
     L.kp1_step.argtypes = [vp, vp, vp, vp, vp, vp, i32]
     L.kp1_observe.argtypes = [vp, vp]
     L.kp1_get_info.argtypes = [vp, C.POINTER(kcfg.InfoView)]
+    L.kp1_eval_accumulate.argtypes = [vp, C.POINTER(EvalBuffers), vp, vp, vp, i32, vp, i32, vp]
     L.kp1_get_reward_components.argtypes = [vp, C.POINTER(vp), C.POINTER(i32)]
     L.kp1_enable_reward_components.argtypes = [vp, i32]
     L.kp1_component_name.argtypes = [i32, i32]

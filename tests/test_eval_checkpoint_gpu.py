@@ -223,3 +223,51 @@ def test_resume_restores_adam_state(tmp_path):
         assert abs(c.policy.flat[idx].item() - expect) <= 2e-6 * max(1.0, abs(expect)), (idx, step)
     for e in (env_a, env_b, env_c):
         e.close()
+
+
+@pytest.mark.parametrize("cfg_name,real,confirm,masked", [("approach_dock_coarse_ready_v1", "f32", 2, False), ("fuzz1_approach", "f32", 0, True),
+                                                          ("fuzz1_approach", "f64", 3, True), ("fuzz2_approach", "f32", 2, False)])
+def test_device_eval_bookkeeping_equals_tensor_expressions(cfg_name, real, confirm, masked):
+    """kp1_eval_accumulate (one launch per env step) against the tensor-expression form of the evaluator's bookkeeping
+    (_run_episodes_reference): 600 episodes from sampled resets under a noisy servo of mixed gains -- episodes succeed and terminate early
+    (the fuzz configs terminate on success), hover around the ready thresholds or time out -- every result and handoff tensor bit for bit."""
+    cfg = load_golden_config(cfg_name)
+    E = 600
+    g = np.random.default_rng(4)
+    gains = torch.tensor(g.choice([0.0, 0.15, 0.5, 0.9], size=E), device="cuda", dtype=torch.float64)[:, None]
+    active = torch.tensor(g.random(E) < 0.8, device="cuda") if masked else None
+
+    def make():
+        env = ArmKinematicVecEnv(cfg, E, seed=5, real=real)
+        dl = torch.tensor(env.config.c.joints.delta_limit[:], device="cuda", dtype=torch.float64) * env.config.c.env.action_delta_scale
+        noise = torch.Generator(device="cuda").manual_seed(9)
+
+        def policy(obs):
+            info = env.info()
+            a = gains * (info["goal_q"].double().t() - info["q"].double().t()) / dl
+            a = a + 0.02 * torch.randn(a.shape, device="cuda", dtype=torch.float64, generator=noise)
+            return a.clamp(-1.5, 1.5).to(env.dtype)       # unclipped range on purpose: |action| is taken before the env clips
+
+        return env, policy
+
+    out = []
+    for fn in (ev.run_episodes, ev._run_episodes_reference):
+        env, policy = make()
+        out.append(fn(env, policy, None, ready_cfg=cfg.c.reward, handoff_confirm_steps=confirm, active=active))
+        env.close()
+    (res, hand), (ref, ref_hand) = out
+    assert set(res) == set(ref)
+    for k in ref:
+        assert res[k].dtype == ref[k].dtype and torch.equal(res[k], ref[k]), k
+    assert bool(ref["ready_hit"].any()) and not bool(ref["ready_hit"].all())          # the scenario exercises the ready bookkeeping ...
+    if cfg.c.termination.terminate_on_success:
+        steps = ref["step_count"][ref["step_count"] > 0]
+        assert int(steps.max()) > int(steps.min()) and bool(ref["success"].any())     # ... and episodes of different lengths
+    if confirm:
+        assert bool(ref_hand["valid"].any()) and not bool(ref_hand["valid"].all())
+        for k in ref_hand:                                   # the reference creates a handoff entry when the first episode hands over
+            assert hand[k].dtype == ref_hand[k].dtype and torch.equal(hand[k], ref_hand[k]), k
+    else:
+        assert hand is None and ref_hand is None
+    if masked:
+        assert torch.equal(res["step_count"][~active], torch.zeros_like(res["step_count"][~active]))
