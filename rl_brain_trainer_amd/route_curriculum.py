@@ -165,26 +165,32 @@ def _roll_one(env: RouteVecEnv, policy: PolicyFn, *, initial_q: np.ndarray, goal
     max_ready_streak = 0
     steps = 0
     done = 0
+    # the episode is a serial dependency chain (one env, the next waypoint starts where this one ends): per step ONE device -> host copy of
+    # the eight scalars the bookkeeping needs (f64, exact) instead of one synchronising read per scalar
+    keys = ("position_error_norm", "orientation_error_norm", "route_q_error_norm", "route_ready", "route_ready_streak", "action_l2", "executed_delta_q_l2")
+    pos = ori = qerr = act = dqn = 0.0
     while not (done & 3):
         action = policy(obs)
         obs, _, d = env.step(action, auto_reset=False)
-        done = int(d[0])
-        steps += 1
         info = env.info()
-        min_pos = min(min_pos, float(info["position_error_norm"][0]))
-        min_ori = min(min_ori, float(info["orientation_error_norm"][0]))
-        min_q = min(min_q, float(info["route_q_error_norm"][0]))
-        if bool(info["route_ready"][0]) and first_ready_step is None:
+        row = torch.stack([info[k][0].double() for k in keys] + [d[0].double()]).cpu().tolist()
+        pos, ori, qerr, ready, streak, act, dqn = row[:7]
+        done = int(row[7])
+        steps += 1
+        min_pos, min_ori, min_q = min(min_pos, pos), min(min_ori, ori), min(min_q, qerr)
+        if ready != 0.0 and first_ready_step is None:
             first_ready_step = steps
-        max_ready_streak = max(max_ready_streak, int(info["route_ready_streak"][0]))
+        max_ready_streak = max(max_ready_streak, int(streak))
+    if steps == 0:   # (cannot happen: a fresh episode is never done) keep the row well defined
+        pos, ori, qerr = float(info["position_error_norm"][0]), float(info["orientation_error_norm"][0]), float(info["route_q_error_norm"][0])
+        act, dqn = float(info["action_l2"][0]), float(info["executed_delta_q_l2"][0])
     st = env.get_state()
     return {
         "route_index": int(goal_index), "success": bool(done & 4), "route_ready_hit": bool(first_ready_step is not None),
         "route_ready_dwell": bool(max_ready_streak >= success_dwell_steps), "first_ready_step": first_ready_step, "max_ready_streak": int(max_ready_streak),
-        "steps": int(steps), "final_position_error": float(info["position_error_norm"][0]),
-        "final_orientation_error": float(info["orientation_error_norm"][0]), "final_q_error": float(info["route_q_error_norm"][0]),
+        "steps": int(steps), "final_position_error": float(pos), "final_orientation_error": float(ori), "final_q_error": float(qerr),
         "min_position_error": float(min_pos), "min_orientation_error": float(min_ori), "min_q_error": float(min_q),
-        "final_action_magnitude": float(info["action_l2"][0]), "final_dq_norm": float(info["executed_delta_q_l2"][0]),
+        "final_action_magnitude": float(act), "final_dq_norm": float(dqn),
         "final_q": st["q"][0].copy(), "final_dq": st["dq"][0].copy(), "final_prev_action": st["prev_action"][0].copy(),
     }
 
