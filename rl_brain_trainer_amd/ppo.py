@@ -282,7 +282,8 @@ class PPO:
         self._perm_rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([int(cfg.seed), self.dist.rank, 0x6B7031])))   # shuffle keys
         self.num_timesteps = 0
         self._needs_reset = True
-        self.last_stats: dict[str, float] = {}
+        self._last_stats_dev: tuple[torch.Tensor, int] | None = None    # (loss sums of the last train() on the device, number of updates)
+        self._last_stats_host: dict[str, float] = {}
         if env.dtype != torch.float32:
             raise ValueError("PPO drives the production f32 env")
         self._mlp = None
@@ -640,8 +641,20 @@ class PPO:
                 n_updates += 1
         if self._mlp is not None:
             stats = self.stats_dev.clone()
-        self.last_stats = dict(zip(("policy_loss", "value_loss", "entropy", "approx_kl"), (stats / max(n_updates, 1)).tolist()))
-        self.last_stats["n_updates"] = n_updates
+        # read back lazily (last_stats): a .tolist() here would make every iteration wait for its own update before the host can enqueue
+        # the next rollout
+        self._last_stats_dev = (stats, n_updates)
+
+    @property
+    def last_stats(self) -> dict[str, float]:
+        """mean policy loss / value loss / entropy / approx_kl over the minibatches of the last train() call, and their number (SB3 logger keys
+        train/policy_gradient_loss, train/value_loss, train/entropy_loss, train/approx_kl); reading it synchronises with that update"""
+        if self._last_stats_dev is not None:
+            stats, n_updates = self._last_stats_dev
+            self._last_stats_host = dict(zip(("policy_loss", "value_loss", "entropy", "approx_kl"), (stats / max(n_updates, 1)).tolist()))
+            self._last_stats_host["n_updates"] = n_updates
+            self._last_stats_dev = None
+        return self._last_stats_host
 
     def _epoch_adv_stats(self, adv, perm, total: int, local_bs: int):
         """(mean, 1/(std + 1e-8)) of the advantages of every minibatch of this epoch, f32 [n_minibatches, 2] on the device.
