@@ -205,6 +205,8 @@ def run_episodes(env: ArmKinematicVecEnv, policy: PolicyFn, reset_options: dict[
     bookkeeping on the device (finals / minima / sums, success, state snapshot, ready streak, first-confirmed handoff snapshot, alive
     mask); the host looks at the alive-episode counter every _ALIVE_CHECK_EVERY steps.  Results are bit-identical to the tensor-expression
     form (_run_episodes_reference; tests/test_eval_checkpoint_gpu.py)."""
+    if not isinstance(env, ArmKinematicVecEnv):
+        raise TypeError("run_episodes drives an ArmKinematicVecEnv (kp1_eval_accumulate reads its handle); the route wrappers have their own evaluator")
     E = env.n_envs
     dev = env.device
     L = native.load()
