@@ -150,7 +150,7 @@ class Dist:
 
     RCCL collectives are captured INSIDE the hipGraphs of the rollout and of the update epoch (``graphs_ok``): with ~100 us of
     kernels per optimiser step an eagerly launched 650 KB all-reduce would leave the GPU idle for its whole host latency 512 times per
-    iteration.  Whether capture works is probed once per process on a 4-float all-reduce (capture, replay, check the sum); any exception
+    iteration.  Whether capture works is probed once per process on a 4-float all-reduce and a 16-byte all-gather (capture, replay, check the results); any exception
     or wrong result selects the eager path on ALL ranks (the verdict is itself all-reduced), a hang is turned into a clear process exit
     by a watchdog.  ``KP1_DIST_GRAPHS=0`` skips the probe and runs eagerly."""
 
@@ -207,7 +207,11 @@ class Dist:
         if ok:
             buf = torch.full((4,), float(self.rank + 1), device=device)
             expect = float(self.world_size * (self.world_size + 1) // 2)
+            # the two collectives the captured graphs contain: the flat gradient all-reduce (update epoch) and the done-byte all-gather (rollout)
+            mine = torch.full((16,), self.rank + 1, dtype=torch.uint8, device=device)
+            gathered = torch.zeros((self.world_size, 16), dtype=torch.uint8, device=device)
             self.dist.all_reduce(buf.clone())          # communicator fully set up before any capture
+            self.dist.all_gather_into_tensor(gathered.clone().view(-1), mine)
             torch.cuda.synchronize(device)
 
             def _hung() -> None:
@@ -222,6 +226,7 @@ class Dist:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self.dist.all_reduce(buf)
+                    self.dist.all_gather_into_tensor(gathered.view(-1), mine)
             except Exception as exc:  # noqa: BLE001 -- capture of a collective is refused in many ways depending on the build
                 print(f"[kp1] rank {self.rank}: RCCL inside hipGraph capture not available ({type(exc).__name__}: {exc}); eager collectives", file=sys.stderr)
                 good = False
@@ -231,9 +236,11 @@ class Dist:
             good = bool(captured.item() > 0.5)
             if good:
                 buf.fill_(float(self.rank + 1))
+                gathered.zero_()
                 g.replay()
                 torch.cuda.synchronize(device)
-                good = bool(torch.all(buf == expect).item())
+                want = torch.arange(1, self.world_size + 1, dtype=torch.uint8, device=device)[:, None].expand(-1, 16)
+                good = bool(torch.all(buf == expect).item()) and bool(torch.equal(gathered, want))
             dog.cancel()
             verdict.fill_(1.0 if good else 0.0)
         self.dist.all_reduce(verdict, op=self.dist.ReduceOp.MIN)   # every rank takes the same path
