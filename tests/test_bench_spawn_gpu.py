@@ -41,9 +41,14 @@ def test_bench_gpus2_spawns_two_ranks():
     assert two["scaling"] == "weak" and two["config"]["ranks_in_sync"] is True
     assert two["config"]["backend"] == "gloo" and two["config"]["done_exchange_steps"] == 16
     assert two["config"]["collectives_in_graph"] is False          # gloo cannot be captured: the eager fallback ran
-    # weak scaling bookkeeping: twice the env steps per PPO iteration; both ranks share one GPU here, so no speed-up is expected --
-    # only that value is computed from all ranks' steps (>= 0.5x and <= 2.2x the single-rank rate on the same card)
-    assert 0.3 * one["value"] <= two["value"] <= 2.2 * one["value"], (one["value"], two["value"])
+    # weak-scaling bookkeeping, as an identity over fields the line itself prints (no ratio of two wall clocks: two gloo ranks on one card
+    # measure the box's host all-reduce latency, not the engine): value = steps * n_steps * envs/GPU * world / (max-over-ranks seconds)
+    for rec in (one, two):
+        c = rec["config"]
+        env_steps = rec["steps"] * c["n_steps"] * c["envs_per_gpu"] * rec["n_gpus"]
+        assert rec["value"] > 0 and rec["ms_per_step"] > 0
+        assert abs(rec["value"] - env_steps / (rec["ms_per_step"] * rec["steps"] * 1e-3)) <= 1e-6 * rec["value"]
+        assert rec["config"]["env_steps_timed"] == env_steps
     assert "finisher" in two and two["finisher"]["value"] > 0
     for rec in (one, two):
         assert rec["roofline"]["frac"] > 0 and rec["roofline"]["optimizer_step_kernels_us"]["mlp_train_tile"] > 0
