@@ -76,7 +76,16 @@ struct DevCfg {
   struct Term { KP1_TERMINATION_FIELDS(KP1_DEV_DECL) } term;
   struct Obs { KP1_OBSERVATION_FIELDS(KP1_DEV_DECL) } obs;
   R lower[NJ], upper[NJ], dlim[NJ];
-  DevFk<R> fk;
+  // The kinematic chain -- q integration (q += clip(action) * delta_limit * scale, joint clip), the FK products and the Euler-angle
+  // extraction -- runs in fp64 on BOTH handles (V51/ee_fk.py:98-134 and arm_kinematic_env.py:237-246 are fp64 in the reference).
+  // Roll and yaw are atan2 of rotation entries of size cos(pitch): an absolute error e in those entries, or in q, becomes e / cos(pitch)
+  // in the angles, so fp32 there (1e-7) cannot hold the 1e-5 pose bar on workspaces that reach pitch -> +-pi/2 (BASELINE configs[3]).
+  // Everything downstream of pose6 (errors, counters, reward, observation) stays in R.
+  struct Kin {
+    double lower[NJ], upper[NJ], dlim[NJ];
+    double action_delta_scale, dock_action_delta_scale;
+    DevFk<double> fk;
+  } kin;
 };
 
 // sampler configuration, always fp64 (reset path only)
@@ -97,7 +106,8 @@ struct DevSampler {
 enum RealField {
   F_Q = 0, F_DQ = 7, F_PREV_ACTION = 14, F_GOAL_Q = 21, F_GOAL_POSE = 28, F_EE_POSE = 34, F_ENTRY = 40,
   F_MIN_POS = 44, F_POS_ERR = 45, F_ORI_ERR = 46, F_EXEC_DQ = 47, F_ACTION_L2 = 48, F_DQ_CHANGE = 49,
-  F_NUM_REAL = 50
+  F_QLO = 50,    // fp32 handle: q = (double)F_Q + (double)F_QLO (F_Q is q rounded to fp32, what every fp32 consumer reads); unused in fp64
+  F_NUM_REAL = 57
 };
 enum IntField { I_STEP = 0, I_DWELL, I_ENTRY, I_DRIFT, I_FLAGS, I_STAGE, I_NUM_INT };
 enum { FLAG_PRE_NEAR_HIT = 1, FLAG_NEAR_HIT = 2, FLAG_SUCCESS = 4 };
@@ -111,6 +121,20 @@ struct EnvState {
   int64_t n;
   __device__ __forceinline__ R& r(int f, int64_t i) const { return real[(int64_t)f * n + i]; }
   __device__ __forceinline__ int32_t& iv(int f, int64_t i) const { return ints[(int64_t)f * n + i]; }
+  // joint position as the kinematic chain carries it (fp64).  fp32 handle: a two-float value, 48 significant bits.
+  __device__ __forceinline__ double q_load(int k, int64_t i) const {
+    if constexpr (sizeof(R) == 4) return (double)r(F_Q + k, i) + (double)r(F_QLO + k, i);
+    else return (double)r(F_Q + k, i);
+  }
+  __device__ __forceinline__ void q_store(int k, int64_t i, double q) const {
+    if constexpr (sizeof(R) == 4) {
+      const float hi = (float)q;
+      r(F_Q + k, i) = (R)hi;
+      r(F_QLO + k, i) = (R)(float)(q - (double)hi);
+    } else {
+      r(F_Q + k, i) = (R)q;
+    }
+  }
 };
 
 // ---- forward kinematics (V51/ee_fk.py:98-134) ----------------------------------------------
@@ -151,6 +175,15 @@ __device__ __forceinline__ void fk_pose6(const DevFk<R>& __restrict__ k, const R
   pose[3] = kp_atan2(Rm[7], Rm[8]);                                              // roll  = atan2(R21, R22)
   pose[4] = kp_atan2(-Rm[6], kp_sqrt(kp_fma(Rm[3], Rm[3], Rm[0] * Rm[0])));      // pitch = atan2(-R20, sqrt(R00^2 + R10^2))
   pose[5] = kp_atan2(Rm[3], Rm[0]);                                              // yaw   = atan2(R10, R00)
+}
+
+// the chain as the handles call it: fp64 constants, fp64 q, pose6 rounded to R once at the end
+template <typename R>
+__device__ __forceinline__ void fk_pose6_kin(const DevFk<double>& __restrict__ k, const double* __restrict__ q, R* __restrict__ pose) {
+  double p64[6];
+  fk_pose6<double>(k, q, p64);
+#pragma unroll
+  for (int e = 0; e < 6; ++e) pose[e] = (R)p64[e];
 }
 
 // KP1/kinematics/pose_utils.py:11-12 wrap_to_pi, numpy floor-mod

@@ -156,6 +156,7 @@ __device__ __forceinline__ void reset_env(const EnvState<R>& st, const DevCfg<R>
                                           int64_t i, float* o) {
   const int64_t n = st.n;
   R q[NJ], dq[NJ], pa[NJ], goal_q[NJ], goal_pose[6], ee[6];
+  double q64[NJ], gq64[NJ];   // the kinematic chain is fp64 on both handles (DevCfg::Kin)
   const bool given_q = (opts.flags & OPT_INITIAL_Q) != 0;
   bool has_dq_pa = false, sampled_goal_pose = false, have_sample = false;
   ResetSample rs;
@@ -163,22 +164,23 @@ __device__ __forceinline__ void reset_env(const EnvState<R>& st, const DevCfg<R>
   bool rng_used = false;
   if (given_q) {
 #pragma unroll
-    for (int k = 0; k < NJ; ++k) q[k] = (R)dclip(opts.initial_q[i * NJ + k], smp.lower[k], smp.upper[k]);
+    for (int k = 0; k < NJ; ++k) q64[k] = dclip(opts.initial_q[i * NJ + k], smp.lower[k], smp.upper[k]);
   } else {
     rng_load(st.rng64, st.rng32, n, i, rng);
     rng_used = true;
     sample_reset<MODE>(smp, handoff, rng, stage_index, rs, has_dq_pa, sampled_goal_pose);
     have_sample = true;
 #pragma unroll
-    for (int k = 0; k < NJ; ++k) q[k] = (R)rs.initial_q[k];
+    for (int k = 0; k < NJ; ++k) q64[k] = rs.initial_q[k];
   }
 #pragma unroll
   for (int k = 0; k < NJ; ++k) {
+    q[k] = (R)q64[k];
     dq[k] = (opts.flags & OPT_INITIAL_DQ) ? (R)opts.initial_dq[i * NJ + k] : ((have_sample && has_dq_pa) ? (R)rs.initial_dq[k] : (R)0);
     pa[k] = (opts.flags & OPT_INITIAL_PREV_ACTION) ? (R)opts.initial_prev_action[i * NJ + k]
                                                    : ((have_sample && has_dq_pa) ? (R)rs.initial_prev_action[k] : (R)0);
   }
-  fk_pose6<R>(cfg.fk, q, ee);
+  fk_pose6_kin<R>(cfg.kin.fk, q64, ee);
   if (opts.flags & OPT_GOAL_POSE6) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) goal_pose[k] = (R)opts.goal_pose6[i * 6 + k];
@@ -186,8 +188,11 @@ __device__ __forceinline__ void reset_env(const EnvState<R>& st, const DevCfg<R>
     for (int k = 0; k < NJ; ++k) goal_q[k] = (opts.flags & OPT_GOAL_Q) ? (R)opts.goal_q[i * NJ + k] : (R)0;
   } else if (opts.flags & OPT_GOAL_Q) {
 #pragma unroll
-    for (int k = 0; k < NJ; ++k) goal_q[k] = (R)dclip(opts.goal_q[i * NJ + k], smp.lower[k], smp.upper[k]);
-    fk_pose6<R>(cfg.fk, goal_q, goal_pose);
+    for (int k = 0; k < NJ; ++k) {
+      gq64[k] = dclip(opts.goal_q[i * NJ + k], smp.lower[k], smp.upper[k]);
+      goal_q[k] = (R)gq64[k];
+    }
+    fk_pose6_kin<R>(cfg.kin.fk, gq64, goal_pose);
   } else if (!given_q) {
 #pragma unroll
     for (int k = 0; k < NJ; ++k) goal_q[k] = (R)rs.goal_q[k];
@@ -195,7 +200,7 @@ __device__ __forceinline__ void reset_env(const EnvState<R>& st, const DevCfg<R>
 #pragma unroll
       for (int k = 0; k < 6; ++k) goal_pose[k] = (R)rs.goal_pose6[k];
     } else {
-      fk_pose6<R>(cfg.fk, goal_q, goal_pose);
+      fk_pose6_kin<R>(cfg.kin.fk, rs.goal_q, goal_pose);
     }
   } else {
     // sample_reachable_target; KP1/kinematics/fk_interface.py:25-32
@@ -205,14 +210,14 @@ __device__ __forceinline__ void reset_env(const EnvState<R>& st, const DevCfg<R>
     sample_joint_configuration(smp, rng, smp.goal_sample_margin_fraction, g);
 #pragma unroll
     for (int k = 0; k < NJ; ++k) goal_q[k] = (R)g[k];
-    fk_pose6<R>(cfg.fk, goal_q, goal_pose);
+    fk_pose6_kin<R>(cfg.kin.fk, g, goal_pose);
   }
   if (rng_used) rng_store(st.rng64, st.rng32, n, i, rng);
   R pe[3], oe[3], pn, on;
   pose_error_norms<R>(ee, goal_pose, pe, oe, &pn, &on);
 #pragma unroll
   for (int k = 0; k < NJ; ++k) {
-    st.r(F_Q + k, i) = q[k];
+    st.q_store(k, i, q64[k]);
     st.r(F_DQ + k, i) = dq[k];
     st.r(F_PREV_ACTION + k, i) = pa[k];
     st.r(F_GOAL_Q + k, i) = goal_q[k];
@@ -269,11 +274,12 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
   const EnvState<R>& st = a.st;
   const R Z = (R)0;
 
-  R act[NJ], q[NJ], dq[NJ], prev_action[NJ], goal[6], ee[6];
+  R act[NJ], dq[NJ], prev_action[NJ], goal[6], ee[6];
+  double q[NJ];   // fp64 kinematic chain (DevCfg::Kin)
 #pragma unroll
   for (int k = 0; k < NJ; ++k) {
     act[k] = kp_clip<R>(a.actions[i * NJ + k], (R)-1, (R)1);  // :214
-    q[k] = st.r(F_Q + k, i);
+    q[k] = st.q_load(k, i);
     dq[k] = st.r(F_DQ + k, i);
     prev_action[k] = st.r(F_PREV_ACTION + k, i);
   }
@@ -304,33 +310,35 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
     for (int k = 0; k < NJ; ++k) act[k] = kp_clip<R>(act[k], -dyn_limit, dyn_limit);
   }
   const bool prev_in_near = is_near_goal<R>(cfg, prev_pos, prev_ori);  // :231
-  R scale = cfg.env.action_delta_scale;                                // :232-236
+  double scale = cfg.kin.action_delta_scale;                           // :232-236
   if constexpr (MODE == KP1_MODE_DOCK) {
-    if (cfg.env.dock_action_delta_scale > Z) scale = cfg.env.dock_action_delta_scale;
+    if (cfg.kin.dock_action_delta_scale > 0.0) scale = cfg.kin.dock_action_delta_scale;
   } else {
     if (cfg.env.dynamic_action_delta_scale_enabled) {  // :530-542
       R mult = interpolate_control<R>(prev_pos, cfg.env.dynamic_action_delta_scale_near_pos_threshold_m,
                                       cfg.env.dynamic_action_delta_scale_far_pos_threshold_m,
                                       cfg.env.dynamic_action_delta_scale_near_multiplier,
                                       cfg.env.dynamic_action_delta_scale_far_multiplier, (R)1);
-      scale = cfg.env.action_delta_scale * kp_max<R>(mult, Z);
+      scale = cfg.kin.action_delta_scale * (double)kp_max<R>(mult, Z);
     }
   }
   R q_next[NJ], dq_next[NJ];
+  double q_next64[NJ];
   R dq_change_ss = Z, dq_ss = Z, prev_dq_ss = Z, act_ss = Z, pact_ss = Z, dact_ss = Z, margin_min = (R)1;
 #pragma unroll
   for (int k = 0; k < NJ; ++k) {
-    R max_dq = cfg.dlim[k] * scale;           // :237
-    R cmd = act[k] * max_dq;                  // :238
-    if constexpr (MODE == KP1_MODE_DOCK) {    // :239-242
+    const double max_dq = cfg.kin.dlim[k] * scale;   // :237
+    double cmd = (double)act[k] * max_dq;            // :238
+    if constexpr (MODE == KP1_MODE_DOCK) {           // :239-242
       if (dyn_dqc > Z) {
-        R lim = max_dq * dyn_dqc;
-        cmd = dq[k] + kp_clip<R>(cmd - dq[k], -lim, lim);
-        cmd = kp_clip<R>(cmd, -max_dq, max_dq);
+        const double lim = max_dq * (double)dyn_dqc, dqk = (double)dq[k];
+        cmd = dqk + dclip(cmd - dqk, -lim, lim);
+        cmd = dclip(cmd, -max_dq, max_dq);
       }
     }
-    q_next[k] = joint_clip<R>(q[k] + cmd, cfg.lower[k], cfg.upper[k]);  // :243
-    dq_next[k] = q_next[k] - q[k];                                   // :244
+    q_next64[k] = joint_clip<double>(q[k] + cmd, cfg.kin.lower[k], cfg.kin.upper[k]);  // :243
+    q_next[k] = (R)q_next64[k];
+    dq_next[k] = (R)(q_next64[k] - q[k]);                                             // :244
     R dd = dq_next[k] - dq[k];
     dq_change_ss += dd * dd;
     dq_ss += dq_next[k] * dq_next[k];
@@ -342,7 +350,7 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
     margin_min = kp_min<R>(margin_min, joint_limit_margin<R>(q_next[k], cfg.lower[k], cfg.upper[k]));  // joint_limits.py:166-174
   }
   R ee_next[6];
-  fk_pose6<R>(cfg.fk, q_next, ee_next);  // :246
+  fk_pose6_kin<R>(cfg.kin.fk, q_next64, ee_next);  // :246
   R curr_pos, curr_ori;
   pose_error_norms<R>(ee_next, goal, pe, oe, &curr_pos, &curr_ori);  // :248-250
   const bool curr_pre = is_pre_near_goal<R>(cfg, curr_pos, curr_ori);
@@ -412,7 +420,7 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
   } else {
 #pragma unroll
     for (int k = 0; k < NJ; ++k) {
-      st.r(F_Q + k, i) = q_next[k];
+      st.q_store(k, i, q_next64[k]);
       st.r(F_DQ + k, i) = dq_next[k];
       st.r(F_PREV_ACTION + k, i) = act[k];
     }
@@ -472,19 +480,21 @@ __global__ void __launch_bounds__(256) kp1_init_kernel(const EnvState<R> st, con
   if (i >= st.n) return;
   for (int f = 0; f < F_NUM_REAL; ++f) st.r(f, i) = (R)0;
   for (int f = 0; f < I_NUM_INT; ++f) st.iv(f, i) = 0;
-  R q[NJ] = {0, 0, 0, 0, 0, 0, 0}, ee[6];
-  fk_pose6<R>(cfg->fk, q, ee);
+  const double q[NJ] = {0, 0, 0, 0, 0, 0, 0};
+  R ee[6];
+  fk_pose6_kin<R>(cfg->kin.fk, q, ee);
   for (int k = 0; k < 6; ++k) st.r(F_EE_POSE + k, i) = ee[k];
   st.r(F_MIN_POS, i) = std::numeric_limits<R>::infinity();
 }
 
 template <typename R>
-__global__ void kp1_fk_kernel(const DevFk<R>* fk, const R* q, R* pose, int64_t n) {
+__global__ void kp1_fk_kernel(const DevFk<double>* fk, const R* q, R* pose, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  R qq[NJ], p[6];
-  for (int k = 0; k < NJ; ++k) qq[k] = q[i * NJ + k];
-  fk_pose6<R>(*fk, qq, p);
+  double qq[NJ];
+  R p[6];
+  for (int k = 0; k < NJ; ++k) qq[k] = (double)q[i * NJ + k];
+  fk_pose6_kin<R>(*fk, qq, p);
   for (int k = 0; k < 6; ++k) pose[i * 6 + k] = p[k];
 }
 
@@ -534,12 +544,13 @@ __global__ void kp1_set_state_kernel(const EnvState<R> st, const DevCfg<R>* cfg,
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= st.n) return;
   if (q) {
-    R qq[NJ], ee[6];
+    double qq[NJ];
+    R ee[6];
     for (int k = 0; k < NJ; ++k) {
-      qq[k] = (R)q[i * NJ + k];
-      st.r(F_Q + k, i) = qq[k];
+      qq[k] = q[i * NJ + k];
+      st.q_store(k, i, qq[k]);
     }
-    fk_pose6<R>(cfg->fk, qq, ee);
+    fk_pose6_kin<R>(cfg->kin.fk, qq, ee);
     for (int k = 0; k < 6; ++k) st.r(F_EE_POSE + k, i) = ee[k];
   }
   if (dq) for (int k = 0; k < NJ; ++k) st.r(F_DQ + k, i) = (R)dq[i * NJ + k];
@@ -569,7 +580,7 @@ __global__ void kp1_get_state_kernel(const EnvState<R> st, double* q, double* dq
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= st.n) return;
   for (int k = 0; k < NJ; ++k) {
-    if (q) q[i * NJ + k] = (double)st.r(F_Q + k, i);
+    if (q) q[i * NJ + k] = st.q_load(k, i);
     if (dq) dq[i * NJ + k] = (double)st.r(F_DQ + k, i);
     if (pa) pa[i * NJ + k] = (double)st.r(F_PREV_ACTION + k, i);
     if (goal_q) goal_q[i * NJ + k] = (double)st.r(F_GOAL_Q + k, i);
@@ -733,8 +744,13 @@ void make_dev_cfg(const kp1_config& c, DevCfg<R>* out) {
     out->lower[i] = (R)c.joints.lower[i];
     out->upper[i] = (R)c.joints.upper[i];
     out->dlim[i] = (R)c.joints.delta_limit[i];
+    out->kin.lower[i] = c.joints.lower[i];
+    out->kin.upper[i] = c.joints.upper[i];
+    out->kin.dlim[i] = c.joints.delta_limit[i];
   }
-  fold_fk<R>(&out->fk);
+  out->kin.action_delta_scale = c.env.action_delta_scale;
+  out->kin.dock_action_delta_scale = c.env.dock_action_delta_scale;
+  fold_fk<double>(&out->kin.fk);
 }
 void make_dev_sampler(const kp1_config& c, int n_handoff, DevSampler* s) {
   std::memset(s, 0, sizeof *s);
@@ -1409,21 +1425,15 @@ int kp1_fk_pose6(int32_t device, int32_t real_type, const void* q_dev, void* pos
   const int block = 256;
   const dim3 grid((unsigned)((n + block - 1) / block));
   void* dfk = nullptr;
-  if (real_type == KP1_REAL_F64) {
-    DevFk<double> fk;
-    fold_fk<double>(&fk);
-    HIP_TRY(hipMalloc(&dfk, sizeof fk));
-    HIP_TRY(hipMemcpy(dfk, &fk, sizeof fk, hipMemcpyHostToDevice));
+  if (real_type != KP1_REAL_F64 && real_type != KP1_REAL_F32) return fail(KP1_ERR_INVALID, "real_type must be KP1_REAL_F32 or KP1_REAL_F64");
+  DevFk<double> fk;   // the chain itself is fp64 for both real types; real_type is the type of q and pose6 in memory
+  fold_fk<double>(&fk);
+  HIP_TRY(hipMalloc(&dfk, sizeof fk));
+  HIP_TRY(hipMemcpy(dfk, &fk, sizeof fk, hipMemcpyHostToDevice));
+  if (real_type == KP1_REAL_F64)
     hipLaunchKernelGGL(kp1_fk_kernel<double>, grid, dim3(block), 0, (hipStream_t)stream, (const DevFk<double>*)dfk, (const double*)q_dev, (double*)pose6_dev, n);
-  } else if (real_type == KP1_REAL_F32) {
-    DevFk<float> fk;
-    fold_fk<float>(&fk);
-    HIP_TRY(hipMalloc(&dfk, sizeof fk));
-    HIP_TRY(hipMemcpy(dfk, &fk, sizeof fk, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(kp1_fk_kernel<float>, grid, dim3(block), 0, (hipStream_t)stream, (const DevFk<float>*)dfk, (const float*)q_dev, (float*)pose6_dev, n);
-  } else {
-    return fail(KP1_ERR_INVALID, "real_type must be KP1_REAL_F32 or KP1_REAL_F64");
-  }
+  else
+    hipLaunchKernelGGL(kp1_fk_kernel<float>, grid, dim3(block), 0, (hipStream_t)stream, (const DevFk<double>*)dfk, (const float*)q_dev, (float*)pose6_dev, n);
   hipError_t le = hipGetLastError();
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   (void)hipFree(dfk);

@@ -81,143 +81,202 @@ def _selected_stages(env_cfg: kcfg.EnvConfig, stage_indices: Sequence[int] | Non
     return [int(np.clip(i, 0, n - 1)) for i in sel]
 
 
-# --------------------------------------------------------------------------------------------- target map
-def _bucketize(values: np.ndarray, lower: np.ndarray, upper: np.ndarray, bins: int) -> list[int]:
-    scaled = (np.asarray(values, dtype=float) - lower) / np.maximum(upper - lower, 1e-9)
-    return np.clip(np.floor(scaled * bins), 0, bins - 1).astype(int).tolist()
+# --------------------------------------------------------------------------------------------- the two maps, column-wise
+# Both maps are a few thousand uniform draws from ONE numpy Generator followed by per-sample arithmetic.  The reference makes the draws one
+# sample at a time; what has to be reproduced is only the ORDER in which doubles leave the generator (the golden maps of
+# tests/golden/coverage_maps.json pin it).  `Generator.random` and `Generator.uniform` both consume exactly one next_double per output element,
+# in C order, and uniform is `low + (high - low) * u` with the product rounded before the add -- so the whole draw sequence of a map is a
+# slicing of one stream of doubles, taken here in blocks (`_DrawStream`), and everything after it is arithmetic on columns.
+class _DrawStream:
+    """next_double stream of `np.random.default_rng(seed)`, drawn in blocks; take / peek / skip address it as one flat sequence"""
+
+    def __init__(self, seed: int, block: int = 8192):
+        self._rng = np.random.default_rng(seed)
+        self._buf = np.empty(0, dtype=float)
+        self._block = block
+
+    def peek(self, count: int) -> np.ndarray:
+        if count > self._buf.shape[0]:
+            self._buf = np.concatenate([self._buf, self._rng.random(max(count - self._buf.shape[0], self._block))])
+        return self._buf[:count]
+
+    def skip(self, count: int) -> None:
+        self.peek(count)
+        self._buf = self._buf[count:]
+
+    def take(self, *shape: int) -> np.ndarray:
+        count = int(np.prod(shape, dtype=np.int64))
+        out = self.peek(count).copy().reshape(shape)
+        self.skip(count)
+        return out
 
 
-def _difficulty(q: np.ndarray, pose6: np.ndarray, margin_min: float) -> float:
-    q_term = min(float(np.linalg.norm(q)) / 4.5, 1.0)
-    ori_term = min(float(np.linalg.norm(pose6[3:])) / np.pi, 1.0)
-    margin_term = 1.0 - float(np.clip(margin_min, 0.0, 1.0))
-    return float(0.45 * q_term + 0.35 * ori_term + 0.20 * margin_term)
+def _scaled(u: np.ndarray, low, high) -> np.ndarray:
+    """numpy's uniform on already-drawn doubles: low + (high - low) * u, product first (distributions.c random_uniform)"""
+    low, high = np.asarray(low, dtype=float), np.asarray(high, dtype=float)
+    return low + (high - low) * u
+
+
+def _stage_targets(stream: _DrawStream, base_q: np.ndarray, noise_q: np.ndarray, count: int, lo: np.ndarray, hi: np.ndarray) -> np.ndarray:
+    """`count` consecutive sample_stage_joint_target draws (envs/curriculum.py:90-101) as one [count, 7] block; a stage without noise draws nothing"""
+    rows = np.broadcast_to(base_q, (count, kcfg.NJ))
+    if np.any(noise_q > 0.0):
+        rows = base_q + _scaled(stream.take(count, kcfg.NJ), -noise_q, noise_q)
+    return np.clip(rows, lo, hi)
+
+
+def _valid_q_block(stream: _DrawStream, count: int, lo: np.ndarray, hi: np.ndarray, margin_fraction: float) -> np.ndarray:
+    """`count` consecutive sample_joint_configuration draws (kinematics/joint_limits.py:138-150)"""
+    margin = np.maximum((hi - lo) * margin_fraction, 1e-6)
+    return _scaled(stream.take(count, kcfg.NJ), lo + margin, hi - margin)
+
+
+def _row_norm(m: np.ndarray) -> np.ndarray:
+    return np.sqrt(np.einsum("ij,ij->i", m, m))
+
+
+def _bin(values: np.ndarray, bins: int) -> np.ndarray:
+    """floor(values * bins) clamped to [0, bins - 1], as integers"""
+    return np.clip(np.floor(values * bins), 0, bins - 1).astype(int)
+
+
+def _span_stats(pos: np.ndarray) -> tuple[list[float], list[float], list[float]]:
+    if not len(pos):
+        zero = [0.0, 0.0, 0.0]
+        return zero, zero, zero
+    mn, mx = pos.min(axis=0), pos.max(axis=0)
+    return (mx - mn).tolist(), mn.tolist(), mx.tolist()
 
 
 def generate_workspace_target_map(env_cfg: kcfg.EnvConfig, *, seed: int, stage_samples_per_stage: int, random_samples: int,
                                   stage_indices: Sequence[int] | None = None, xyz_bins: int = 8, ori_bins: int = 6, q_l2_bins: int = 6,
                                   fk: FkFn | None = None) -> tuple[list[dict[str, Any]], dict[str, Any]]:
+    """workspace/workspace_target_map.py:76-157.  Draw order: for every selected stage its `stage_samples_per_stage` goal draws, then the
+    random valid-q draws (margin 0.08)."""
     fk = fk or _device_fk()
     lo, hi = _limits(env_cfg)
-    rng = np.random.default_rng(seed)
-    selected = _selected_stages(env_cfg, stage_indices)
-    raw: list[tuple[np.ndarray, int | None, str]] = []
-    for stage_id in selected:
-        _, _, goal_q, goal_noise = _stage_arrays(env_cfg, stage_id)
-        for _ in range(max(stage_samples_per_stage, 0)):
-            raw.append((sample_stage_joint_target(rng, goal_q, goal_noise, lo, hi), stage_id, "stage_distribution"))
-    for _ in range(max(random_samples, 0)):
-        raw.append((sample_joint_configuration(rng, lo, hi, margin_fraction=0.08), None, "random_valid_q"))
+    stream = _DrawStream(seed)
+    stages = _selected_stages(env_cfg, stage_indices)
+    per_stage, n_random = max(stage_samples_per_stage, 0), max(random_samples, 0)
+    blocks = [_stage_targets(stream, *_stage_arrays(env_cfg, sid)[2:], per_stage, lo, hi) for sid in stages]
+    blocks.append(_valid_q_block(stream, n_random, lo, hi, 0.08))
+    q = np.concatenate(blocks, axis=0) if blocks else np.zeros((0, kcfg.NJ))
+    n = q.shape[0]
+    stage_col: list[int | None] = [sid for sid in stages for _ in range(per_stage)] + [None] * n_random
+    kind_col = ["stage_distribution"] * (n - n_random) + ["random_valid_q"] * n_random
 
-    q_all = np.vstack([r[0] for r in raw]) if raw else np.zeros((0, kcfg.NJ))
-    poses = fk(q_all)
-    if len(poses):
-        xyz_lower = poses[:, :3].min(axis=0) - 1e-6
-        xyz_upper = poses[:, :3].max(axis=0) + 1e-6
+    pose = fk(q)
+    pos, rpy = pose[:, :3], pose[:, 3:]
+    if n:
+        box_lo, box_hi = pos.min(axis=0) - 1e-6, pos.max(axis=0) + 1e-6
     else:
-        xyz_lower, xyz_upper = np.asarray([-1.0, -1.0, 0.0]), np.asarray([1.0, 1.0, 2.0])
+        box_lo, box_hi = np.array([-1.0, -1.0, 0.0]), np.array([1.0, 1.0, 2.0])
+    margin = joint_limit_margin(q, lo, hi).min(axis=1) if n else np.zeros(0)
+    q_l2, ori_l2 = _row_norm(q), _row_norm(rpy)
+    cell = _bin((pos - box_lo) / np.maximum(box_hi - box_lo, 1e-9), xyz_bins)
+    ori_cell, q_cell = _bin(ori_l2 / np.pi, ori_bins), _bin(q_l2 / 4.5, q_l2_bins)
+    # difficulty: 0.45 joint distance from home + 0.35 orientation magnitude + 0.20 closeness to a joint limit, each in [0, 1]
+    difficulty = 0.45 * np.minimum(q_l2 / 4.5, 1.0) + 0.35 * np.minimum(ori_l2 / np.pi, 1.0) + 0.20 * (1.0 - np.clip(margin, 0.0, 1.0))
+    labels = [f"x{cx}_y{cy}_z{cz}_o{co}_q{cq}" for (cx, cy, cz), co, cq in zip(cell.tolist(), ori_cell.tolist(), q_cell.tolist())]
 
-    samples: list[dict[str, Any]] = []
-    for idx, (q, stage_id, source_type) in enumerate(raw):
-        pose6 = poses[idx]
-        margin_min = float(np.min(joint_limit_margin(q, lo, hi)))
-        xyz_bucket = _bucketize(pose6[:3], xyz_lower, xyz_upper, xyz_bins)
-        ori_bucket = int(np.clip(np.floor(float(np.linalg.norm(pose6[3:])) / np.pi * ori_bins), 0, ori_bins - 1))
-        q_bucket = int(np.clip(np.floor(float(np.linalg.norm(q)) / 4.5 * q_l2_bins), 0, q_l2_bins - 1))
-        samples.append({
-            "target_id": f"target_{idx:06d}", "q_target": q.astype(float).tolist(), "ee_target_position": pose6[:3].astype(float).tolist(),
-            "ee_target_orientation": pose6[3:].astype(float).tolist(), "stage_id": stage_id, "source_type": source_type,
-            "bucket_id": f"x{xyz_bucket[0]}_y{xyz_bucket[1]}_z{xyz_bucket[2]}_o{ori_bucket}_q{q_bucket}", "xyz_bucket": xyz_bucket,
-            "orientation_bucket": ori_bucket, "joint_l2_bucket": q_bucket, "joint_limit_margin_min": margin_min,
-            "reachability_flag": bool(margin_min > 0.0), "difficulty_score": _difficulty(q, pose6, margin_min),
-            "previous_eval_success_rate": None, "previous_failure_reason_counts": None,
-        })
-
-    q_stack = np.vstack([np.asarray(s["q_target"], dtype=float) for s in samples]) if samples else np.zeros((0, kcfg.NJ))
-    pos_stack = np.vstack([np.asarray(s["ee_target_position"], dtype=float) for s in samples]) if samples else np.zeros((0, 3))
+    q_l, pos_l, rpy_l, cell_l = q.tolist(), pos.tolist(), rpy.tolist(), cell.tolist()
+    samples = [{
+        "target_id": f"target_{k:06d}", "q_target": q_l[k], "ee_target_position": pos_l[k], "ee_target_orientation": rpy_l[k],
+        "stage_id": stage_col[k], "source_type": kind_col[k], "bucket_id": labels[k], "xyz_bucket": cell_l[k],
+        "orientation_bucket": int(ori_cell[k]), "joint_l2_bucket": int(q_cell[k]), "joint_limit_margin_min": float(margin[k]),
+        "reachability_flag": bool(margin[k] > 0.0), "difficulty_score": float(difficulty[k]),
+        "previous_eval_success_rate": None, "previous_failure_reason_counts": None,
+    } for k in range(n)]
+    span, box_min, box_max = _span_stats(pos)
     summary = {
-        "seed": int(seed), "total_target_count": len(samples), "valid_target_count": sum(1 for s in samples if s["reachability_flag"]),
-        "rejected_target_count": 0, "stage_indices": selected,
-        "xyz_span": (pos_stack.max(axis=0) - pos_stack.min(axis=0)).tolist() if len(pos_stack) else [0.0, 0.0, 0.0],
-        "xyz_min": pos_stack.min(axis=0).tolist() if len(pos_stack) else [0.0, 0.0, 0.0],
-        "xyz_max": pos_stack.max(axis=0).tolist() if len(pos_stack) else [0.0, 0.0, 0.0],
-        "q_l2_range": [float(np.min(np.linalg.norm(q_stack, axis=1))), float(np.max(np.linalg.norm(q_stack, axis=1)))] if len(q_stack) else [0.0, 0.0],
-        "joint_limit_margin_min": float(min((s["joint_limit_margin_min"] for s in samples), default=0.0)),
-        "joint_limit_margin_mean": float(np.mean([s["joint_limit_margin_min"] for s in samples])) if samples else 0.0,
-        "bucket_count": len({s["bucket_id"] for s in samples}),
+        "seed": int(seed), "total_target_count": n, "valid_target_count": int(np.count_nonzero(margin > 0.0)), "rejected_target_count": 0,
+        "stage_indices": stages, "xyz_span": span, "xyz_min": box_min, "xyz_max": box_max,
+        "q_l2_range": [float(q_l2.min()), float(q_l2.max())] if n else [0.0, 0.0],
+        "joint_limit_margin_min": float(margin.min()) if n else 0.0, "joint_limit_margin_mean": float(margin.mean()) if n else 0.0,
+        "bucket_count": len(set(labels)),
         "stage_is_workspace_note": "Stage IDs are difficulty shells, not the full continuous workspace.",
     }
     return samples, summary
 
 
-# --------------------------------------------------------------------------------------------- start-state map
-def _start_bucket_id(pose6: np.ndarray, q: np.ndarray, margin_min: float) -> str:
-    x = int(np.clip(np.floor((pose6[0] + 1.0) / 2.0 * 8), 0, 7))
-    y = int(np.clip(np.floor((pose6[1] + 1.0) / 2.0 * 8), 0, 7))
-    z = int(np.clip(np.floor((pose6[2]) / 2.0 * 6), 0, 5))
-    q_bucket = int(np.clip(np.floor(np.linalg.norm(q) / 4.5 * 6), 0, 5))
-    m_bucket = int(np.clip(np.floor(margin_min * 5), 0, 4))
-    return f"x{x}_y{y}_z{z}_q{q_bucket}_m{m_bucket}"
-
-
-def _stability_score(margin_min: float, dq: np.ndarray, prev_action: np.ndarray) -> float:
-    motion = min(float(np.linalg.norm(dq)) + float(np.linalg.norm(prev_action)), 1.0)
-    return float(0.7 * np.clip(margin_min, 0.0, 1.0) + 0.3 * (1.0 - motion))
+def _coin_and_noise(stream: _DrawStream, count: int, heads_draws: bool, tails_draws: bool, p_heads: float = 0.65) -> tuple[np.ndarray, np.ndarray]:
+    """`count` consecutive [one coin double, then a 7-vector of doubles if the branch the coin selects has noise].  Returns (heads[count],
+    doubles[count, 7]; rows of a branch without noise are unused).  With both branches alike the records have a fixed length and the block is
+    one reshape; otherwise a record's position depends on the coins before it and the offsets are walked over the already-drawn doubles."""
+    nj = kcfg.NJ
+    if heads_draws == tails_draws:
+        rec = stream.take(count, 1 + nj * int(heads_draws))
+        return rec[:, 0] < p_heads, (rec[:, 1:] if heads_draws else np.zeros((count, nj)))
+    flat = stream.peek(count * (1 + nj))
+    starts = np.empty(count, dtype=np.int64)
+    at = 0
+    for k in range(count):
+        starts[k] = at
+        at += 1 + nj * int(heads_draws if flat[at] < p_heads else tails_draws)
+    heads = flat[starts] < p_heads
+    has = np.where(heads, heads_draws, tails_draws)
+    doubles = flat[np.minimum(starts[:, None] + 1 + np.arange(nj), flat.shape[0] - 1)] * has[:, None]
+    stream.skip(at)
+    return heads, doubles
 
 
 def generate_workspace_start_state_map(env_cfg: kcfg.EnvConfig, *, seed: int, stage_samples_per_stage: int, random_samples: int,
                                        stage_indices: Sequence[int] | None = None, dq_noise: float = 0.001, prev_action_noise: float = 0.03,
                                        fk: FkFn | None = None) -> tuple[list[dict[str, Any]], dict[str, Any]]:
+    """workspace/workspace_start_state_map.py:62-134.  Row 0 is the home pose.  Draw order: per selected stage and sample a coin (< 0.65: the
+    stage's goal distribution, a "successful_rollout"; else its start distribution, "near_target" from stage 6 on) followed by that
+    distribution's draw; then the random valid-q draws (margin 0.10); then, for EVERY row in row order (home included, whose values are then
+    discarded), a dq vector and a prev_action vector."""
     fk = fk or _device_fk()
     lo, hi = _limits(env_cfg)
-    rng = np.random.default_rng(seed)
-    selected = _selected_stages(env_cfg, stage_indices)
-    raw: list[tuple[np.ndarray, str, int | None, str | None]] = [(np.zeros(kcfg.NJ, dtype=float), "home", 0, None)]
-    for stage_id in selected:
-        start_q, start_noise, goal_q, goal_noise = _stage_arrays(env_cfg, stage_id)
-        for sample_idx in range(max(stage_samples_per_stage, 0)):
-            if rng.random() < 0.65:
-                q = sample_stage_joint_target(rng, goal_q, goal_noise, lo, hi)
-                source = "successful_rollout"
-            else:
-                q = sample_stage_joint_target(rng, start_q, start_noise, lo, hi)
-                source = "near_target" if stage_id >= 6 else "successful_rollout"
-            raw.append((q, source, stage_id, f"stage{stage_id:02d}_synthetic_{sample_idx:04d}"))
-    for sample_idx in range(max(random_samples, 0)):
-        raw.append((sample_joint_configuration(rng, lo, hi, margin_fraction=0.10), "random_valid_q", None, f"random_{sample_idx:04d}"))
+    nj = kcfg.NJ
+    stream = _DrawStream(seed)
+    stages = _selected_stages(env_cfg, stage_indices)
+    per_stage, n_random = max(stage_samples_per_stage, 0), max(random_samples, 0)
+    q_blocks, kind_col, stage_col, run_col = [np.zeros((1, nj))], ["home"], [0], [None]
+    for sid in stages:
+        start_q, start_noise, goal_q, goal_noise = _stage_arrays(env_cfg, sid)
+        goal_draws, start_draws = bool(np.any(goal_noise > 0.0)), bool(np.any(start_noise > 0.0))
+        heads, u7 = _coin_and_noise(stream, per_stage, goal_draws, start_draws)
+        from_goal = goal_q + (_scaled(u7, -goal_noise, goal_noise) if goal_draws else 0.0)
+        from_start = start_q + (_scaled(u7, -start_noise, start_noise) if start_draws else 0.0)
+        q_blocks.append(np.clip(np.where(heads[:, None], from_goal, from_start), lo, hi))
+        tails_kind = "near_target" if sid >= 6 else "successful_rollout"
+        kind_col += ["successful_rollout" if h else tails_kind for h in heads.tolist()]
+        stage_col += [sid] * per_stage
+        run_col += [f"stage{sid:02d}_synthetic_{k:04d}" for k in range(per_stage)]
+    q_blocks.append(_valid_q_block(stream, n_random, lo, hi, 0.10))
+    kind_col += ["random_valid_q"] * n_random
+    stage_col += [None] * n_random
+    run_col += [f"random_{k:04d}" for k in range(n_random)]
+    q = np.concatenate(q_blocks, axis=0)
+    n = q.shape[0]
 
-    # the dq / prev_action draws follow ALL q draws, two vector draws per sample in sample order (home included, then zeroed)
-    motion = []
-    for _q, source, _s, _r in raw:
-        dq = rng.uniform(-dq_noise, dq_noise, size=kcfg.NJ)
-        prev_action = rng.uniform(-prev_action_noise, prev_action_noise, size=kcfg.NJ)
-        if source == "home":
-            dq = np.zeros(kcfg.NJ, dtype=float)
-            prev_action = np.zeros(kcfg.NJ, dtype=float)
-        motion.append((dq, prev_action))
-    poses = fk(np.vstack([r[0] for r in raw]))
+    motion = stream.take(n, 2 * nj)
+    dq, prev_action = _scaled(motion[:, :nj], -dq_noise, dq_noise), _scaled(motion[:, nj:], -prev_action_noise, prev_action_noise)
+    dq[0], prev_action[0] = 0.0, 0.0                                  # the home row is at rest
 
-    samples: list[dict[str, Any]] = []
-    for idx, (q, source, stage_id, rollout_id) in enumerate(raw):
-        dq, prev_action = motion[idx]
-        pose6 = poses[idx]
-        margin_min = float(np.min(joint_limit_margin(q, lo, hi)))
-        samples.append({
-            "start_id": f"start_{idx:06d}", "q_start": q.astype(float).tolist(), "dq_start": dq.astype(float).tolist(),
-            "prev_action": prev_action.astype(float).tolist(), "ee_position": pose6[:3].astype(float).tolist(),
-            "ee_orientation": pose6[3:].astype(float).tolist(), "source_type": source, "source_stage": stage_id, "source_rollout_id": rollout_id,
-            "stability_score": _stability_score(margin_min, dq, prev_action), "joint_limit_margin_min": margin_min,
-            "bucket_id": _start_bucket_id(pose6, q, margin_min),
-        })
-    source_counts: dict[str, int] = {}
-    for s in samples:
-        source_counts[s["source_type"]] = source_counts.get(s["source_type"], 0) + 1
-    pos_stack = np.vstack([np.asarray(s["ee_position"], dtype=float) for s in samples])
+    pose = fk(q)
+    pos, rpy = pose[:, :3], pose[:, 3:]
+    margin = joint_limit_margin(q, lo, hi).min(axis=1)
+    # stability: 0.7 joint-limit margin + 0.3 stillness (|dq| + |prev_action| saturating at 1)
+    stability = 0.7 * np.clip(margin, 0.0, 1.0) + 0.3 * (1.0 - np.minimum(_row_norm(dq) + _row_norm(prev_action), 1.0))
+    cells = np.stack([_bin((pos[:, 0] + 1.0) / 2.0, 8), _bin((pos[:, 1] + 1.0) / 2.0, 8), _bin(pos[:, 2] / 2.0, 6), _bin(_row_norm(q) / 4.5, 6),
+                      _bin(margin, 5)], axis=1).tolist()
+    labels = [f"x{c[0]}_y{c[1]}_z{c[2]}_q{c[3]}_m{c[4]}" for c in cells]
+
+    q_l, dq_l, pa_l, pos_l, rpy_l = q.tolist(), dq.tolist(), prev_action.tolist(), pos.tolist(), rpy.tolist()
+    samples = [{
+        "start_id": f"start_{k:06d}", "q_start": q_l[k], "dq_start": dq_l[k], "prev_action": pa_l[k], "ee_position": pos_l[k],
+        "ee_orientation": rpy_l[k], "source_type": kind_col[k], "source_stage": stage_col[k], "source_rollout_id": run_col[k],
+        "stability_score": float(stability[k]), "joint_limit_margin_min": float(margin[k]), "bucket_id": labels[k],
+    } for k in range(n)]
+    kinds, kind_counts = np.unique(np.array(kind_col), return_counts=True)
+    first_seen = sorted(range(len(kinds)), key=lambda j: kind_col.index(str(kinds[j])))      # dict order of the reference: first occurrence
     summary = {
-        "seed": int(seed), "total_start_count": len(samples), "source_counts": source_counts, "bucket_count": len({s["bucket_id"] for s in samples}),
-        "xyz_span": (pos_stack.max(axis=0) - pos_stack.min(axis=0)).tolist(),
-        "joint_limit_margin_min": float(min((s["joint_limit_margin_min"] for s in samples), default=0.0)),
-        "joint_limit_margin_mean": float(np.mean([s["joint_limit_margin_min"] for s in samples])),
+        "seed": int(seed), "total_start_count": n, "source_counts": {str(kinds[j]): int(kind_counts[j]) for j in first_seen},
+        "bucket_count": len(set(labels)), "xyz_span": _span_stats(pos)[0],
+        "joint_limit_margin_min": float(margin.min()), "joint_limit_margin_mean": float(margin.mean()),
         "random_start_note": "Start states intentionally include non-home q states; this is the core distinction from prior home-start stage sweeps.",
     }
     return samples, summary

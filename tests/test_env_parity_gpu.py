@@ -281,7 +281,8 @@ def test_config4_randomstart_shard_8192_f32():
     assert len(np.unique(ora.field("last_reset_stage"))) > 3          # the pair sampler really mixes target stages
     arng = np.random.default_rng(4)
     dl = np.array(cfg.c.joints.delta_limit[:]) * cfg.c.env.action_delta_scale
-    worst_pos = worst_ori = worst_perr = worst_rot = 0.0
+    worst_pos = worst_ori = worst_perr = worst_oerr = worst_rot = 0.0
+    min_cos = 1.0
     for t in range(160 + 6):
         a = arng.uniform(-1.0, 1.0, size=(n, 7)).astype(np.float32)
         goal_q, q = ora.field("goal_q"), ora.field("q")
@@ -296,24 +297,23 @@ def test_config4_randomstart_shard_8192_f32():
         ee_d = info["ee_pose6"].double().cpu().numpy().T
         d = np.abs(ee_d - ee_o)
         d[:, 3:] = np.abs((d[:, 3:] + np.pi) % (2 * np.pi) - np.pi)
-        # This workspace reaches pitch -> +-pi/2, where roll and yaw are ill-conditioned functions of the rotation: they come from atan2 of matrix
-        # entries of size cos(pitch), so an fp32 pose6 carries independent errors of ~1e-7 / cos(pitch) in roll and in yaw (measured: 8e-4 rad at
-        # cos(pitch) = 2.4e-3) and the orientation those fp32 angles stand for is off by the same amount.  That is a property of storing Euler
-        # angles in fp32, not of the FK arithmetic: the 1e-5 bar is held by position, by pitch, and by roll / yaw / the rotation angle between the
-        # two orientations SCALED by cos(pitch); the stage-5 test above (pitch far from +-pi/2) holds it on the raw components.
-        cond = 1.0 / np.maximum(np.abs(np.cos(ee_o[:, 4])), 1e-6)
-        worst_rot = max(worst_rot, float((_geodesic_angle(ee_d[:, 3:], ee_o[:, 3:]) / cond).max()))
-        assert float(d[:, 4].max()) <= F32_POSE_TOL, t
-        worst_pos, worst_ori = max(worst_pos, d[:, :3].max()), max(worst_ori, float((d[:, 3:] / cond[:, None]).max()))
+        # This workspace reaches pitch -> +-pi/2 (cos(pitch) down to 2.4e-3 on this seed), where roll and yaw are atan2 of rotation entries of
+        # size cos(pitch): the fp32 handle carries q and the FK chain in fp64 (csrc/kp1_device.hpp DevCfg::Kin) and rounds pose6 to fp32 once,
+        # so the RAW components, and the rotation angle between the two orientations, hold the 1e-5 bar here too.
+        min_cos = min(min_cos, float(np.abs(np.cos(ee_o[:, 4])).min()))
+        worst_rot = max(worst_rot, float(_geodesic_angle(ee_d[:, 3:], ee_o[:, 3:]).max()))
+        worst_pos, worst_ori = max(worst_pos, d[:, :3].max()), max(worst_ori, float(d[:, 3:].max()))
         live = ora.field("episode_step") > 0     # envs that did not just auto-reset: their info norms are those of this step
         perr_o = np.linalg.norm(ora.field("goal_pose6")[:, :3] - ora.field("ee_pose6")[:, :3], axis=1)   # pose_utils.py:11-30
+        oerr_o = np.linalg.norm((ora.field("goal_pose6")[:, 3:] - ora.field("ee_pose6")[:, 3:] + np.pi) % (2 * np.pi) - np.pi, axis=1)
         if live.any():   # (at step 160 every env of a no-termination config resets at once)
             worst_perr = max(worst_perr, float(np.max(np.abs(info["position_error_norm"].double().cpu().numpy() - perr_o)[live])))
+            worst_oerr = max(worst_oerr, float(np.max(np.abs(info["orientation_error_norm"].double().cpu().numpy() - oerr_o)[live])))
         assert np.array_equal(info["stage_index"].cpu().numpy(), ora.field("last_reset_stage")), t
         assert np.array_equal(info["step_count"].cpu().numpy(), ora.field("episode_step")), t
     assert int(ora.field("episode_step").max()) < 160                      # every env went through at least one auto-reset
-    assert worst_pos <= F32_POSE_TOL and worst_rot <= F32_POSE_TOL and worst_ori <= F32_POSE_TOL and worst_perr <= F32_POSE_TOL, \
-        (worst_pos, worst_rot, worst_ori, worst_perr)
+    assert min_cos < 0.01, min_cos                                         # the near-gimbal-lock poses really occur in this shard
+    assert max(worst_pos, worst_rot, worst_ori, worst_perr, worst_oerr) <= F32_POSE_TOL, (worst_pos, worst_rot, worst_ori, worst_perr, worst_oerr)
     assert np.array_equal(env.rng_state(), np.array([orc.rng_words(ora.envs[i].rng) for i in range(n)]))
     env.close()
     small.close()

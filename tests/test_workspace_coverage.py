@@ -80,6 +80,27 @@ def test_summaries_bucket_metrics_and_priorities(gold):
         wc.select_pairs([], mode="nope", limit=1, rng=np.random.default_rng(0))
 
 
+@pytest.mark.parametrize("heads_draws,tails_draws", [(True, True), (False, False), (True, False), (False, True)])
+def test_draw_stream_reproduces_sequential_generator_calls(heads_draws, tails_draws):
+    """the block-drawn stream of the map generators == the reference's call sequence on one Generator: a scalar `random()` coin, then a
+    7-vector `uniform(-noise, noise)` only when the chosen branch has noise, then scalar-bound `uniform(-s, s, size=7)` draws"""
+    seed, count = 1234, 57
+    noise = np.linspace(0.01, 0.07, 7)
+    rng = np.random.default_rng(seed)
+    coins, vecs = [], []
+    for _ in range(count):
+        heads = rng.random() < 0.65
+        coins.append(heads)
+        vecs.append(rng.uniform(low=-noise, high=noise) if (heads_draws if heads else tails_draws) else np.zeros(7))
+    tail = np.stack([rng.uniform(-0.03, 0.03, size=7) for _ in range(5)])
+    stream = wc._DrawStream(seed, block=64)
+    heads, u7 = wc._coin_and_noise(stream, count, heads_draws, tails_draws)
+    assert heads.tolist() == coins
+    used = np.where(heads, heads_draws, tails_draws)
+    assert np.array_equal(np.where(used[:, None], wc._scaled(u7, -noise, noise), 0.0), np.stack(vecs))
+    assert np.array_equal(wc._scaled(stream.take(5, 7), -0.03, 0.03), tail)
+
+
 @pytest.mark.gpu
 def test_maps_with_device_fk_match_reference(gold):
     _check_maps(gold, None)
