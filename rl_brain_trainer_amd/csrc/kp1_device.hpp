@@ -141,21 +141,45 @@ struct EnvState {
 // Bit-reproducibility: contraction is off and every multiply-add is an explicit fma, so the same q gives the same
 // pose bits at every call site (reset, step, set_state).  A zero action therefore leaves the pose error exactly
 // unchanged, as in the reference, and cannot bump the drift counter through last-bit noise.
-template <typename R>
-__device__ __forceinline__ void fk_pose6(const DevFk<R>& __restrict__ k, const R* __restrict__ q, R* __restrict__ pose) {
+// fp64 sin and cos of a joint angle for the fp32 handle's chain: |x| <= 64 (joint limits are inside +-2 pi), so the argument reduction is
+// two fused steps against a 33-bit / tail split of pi/2 (n * PIO2_HI is exact for |n| < 2^20) and needs no large-argument path; kernels
+// are the fdlibm k_sin / k_cos minimax polynomials on [-pi/4, pi/4] (Sun Microsystems' public coefficients; < 1 ulp).  ~40 instructions
+// against ~130 for the general-argument library sincos.
+__device__ __forceinline__ void kp_sincos_kin(double x, double* s, double* c) {
+  const double n = __builtin_rint(x * 6.36619772367581382433e-01);
+  double r = __builtin_fma(-n, 1.57079632673412561417e+00, x);
+  r = __builtin_fma(-n, 6.07710050650619224932e-11, r);
+  const double z = r * r, w = z * z;
+  const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * 2.75573137070700676789e-06) +
+                    z * w * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10);
+  const double sn = __builtin_fma(z * r, __builtin_fma(z, ps, -1.66666666666666324348e-01), r);
+  const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * 2.48015872894767294178e-05)) +
+                    (w * w) * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11));
+  const double hz = 0.5 * z, om = 1.0 - hz;
+  const double cs = om + (((1.0 - om) - hz) + z * pc);
+  const int quad = (int)n;
+  const double a = (quad & 1) ? cs : sn, b = (quad & 1) ? sn : cs;
+  *s = (quad & 2) ? -a : a;
+  *c = ((quad + 1) & 2) ? -b : b;
+}
+
+// Rotation and position of the chain.  FAST selects kp_sincos_kin (fp32 handle); the fp64 handle keeps the library sincos it is pinned with.
+template <typename R, bool FAST>
+__device__ __forceinline__ void fk_chain(const DevFk<R>& __restrict__ k, const R* __restrict__ q, R* __restrict__ p, R* __restrict__ Rm) {
 #pragma clang fp contract(off)
-  R Rm[9], p[3];
   R s, c;
   // joint 0 (prismatic) + joint 1 origin: pure translation
 #pragma unroll
   for (int i = 0; i < 3; ++i) p[i] = kp_fma(k.v0[i], q[0], k.p01[i]);
-  kp_sincos(q[1], &s, &c);
+  if constexpr (FAST) kp_sincos_kin(q[1], &s, &c);
+  else kp_sincos(q[1], &s, &c);
 #pragma unroll
   for (int e = 0; e < 9; ++e) Rm[e] = kp_fma(s, k.ks[0][e], kp_fma(c, k.kc[0][e], k.k1[0][e]));
 #pragma unroll
   for (int j = 2; j < NJ; ++j) {
     const int m = j - 1;
-    kp_sincos(q[j], &s, &c);
+    if constexpr (FAST) kp_sincos_kin(q[j], &s, &c);
+    else kp_sincos(q[j], &s, &c);
     R D[9], Rn[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e) D[e] = kp_fma(s, k.ks[m][e], kp_fma(c, k.kc[m][e], k.k1[m][e]));
@@ -169,6 +193,13 @@ __device__ __forceinline__ void fk_pose6(const DevFk<R>& __restrict__ k, const R
 #pragma unroll
     for (int e = 0; e < 9; ++e) Rm[e] = Rn[e];
   }
+}
+
+template <typename R>
+__device__ __forceinline__ void fk_pose6(const DevFk<R>& __restrict__ k, const R* __restrict__ q, R* __restrict__ pose) {
+#pragma clang fp contract(off)
+  R Rm[9], p[3];
+  fk_chain<R, false>(k, q, p, Rm);
   pose[0] = p[0];
   pose[1] = p[1];
   pose[2] = p[2];
@@ -177,13 +208,27 @@ __device__ __forceinline__ void fk_pose6(const DevFk<R>& __restrict__ k, const R
   pose[5] = kp_atan2(Rm[3], Rm[0]);                                              // yaw   = atan2(R10, R00)
 }
 
-// the chain as the handles call it: fp64 constants, fp64 q, pose6 rounded to R once at the end
+// The chain as the handles call it: fp64 constants and fp64 q on both.
+//   fp64 handle: fk_pose6<double> as is.
+//   fp32 handle: fp64 products (the small entries of a near-gimbal-lock rotation keep their RELATIVE accuracy), then the three angles from
+//   the entries rounded to fp32: atan2 is a function of the ratio, an fp32 ratio costs <= 1.2e-7 relative, i.e. <= 6e-8 rad -- below the
+//   fp32 spacing of the angle it is stored as.  Same bits at every call site (reset, step, set_state), as above.
 template <typename R>
 __device__ __forceinline__ void fk_pose6_kin(const DevFk<double>& __restrict__ k, const double* __restrict__ q, R* __restrict__ pose) {
-  double p64[6];
-  fk_pose6<double>(k, q, p64);
-#pragma unroll
-  for (int e = 0; e < 6; ++e) pose[e] = (R)p64[e];
+  if constexpr (sizeof(R) == 8) {
+    fk_pose6<double>(k, q, pose);
+  } else {
+#pragma clang fp contract(off)
+    double Rm[9], p[3];
+    fk_chain<double, true>(k, q, p, Rm);
+    const float r0 = (float)Rm[0], r3 = (float)Rm[3], r6 = (float)Rm[6], r7 = (float)Rm[7], r8 = (float)Rm[8];
+    pose[0] = (R)p[0];
+    pose[1] = (R)p[1];
+    pose[2] = (R)p[2];
+    pose[3] = atan2f(r7, r8);
+    pose[4] = atan2f(-r6, sqrtf(__builtin_fmaf(r3, r3, r0 * r0)));
+    pose[5] = atan2f(r3, r0);
+  }
 }
 
 // KP1/kinematics/pose_utils.py:11-12 wrap_to_pi, numpy floor-mod
