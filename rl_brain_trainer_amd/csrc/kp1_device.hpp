@@ -38,6 +38,12 @@ __device__ __forceinline__ bool kp_isfinite(float a) { return isfinite(a); }
 __device__ __forceinline__ bool kp_isfinite(double a) { return isfinite(a); }
 __device__ __forceinline__ float kp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double kp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// Quotients of the R-typed arithmetic downstream of pose6 (normalisers, margins, reward ratios).  fp64 handle: IEEE division, as the
+// reference.  fp32 handle: v_rcp_f32 (1 ulp) and a multiply -- 2 instructions instead of the 10 of the correctly rounded fp32 division
+// sequence (48 of them on the step path = a tenth of its instructions); the result differs from the rounded quotient by <= 2 ulp, far
+// inside the fp32 handle's tolerances (observations 2e-6, rewards 1e-5 relative).
+__device__ __forceinline__ float kp_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ double kp_div(double a, double b) { return a / b; }
 template <typename R> __device__ __forceinline__ R kp_max(R a, R b) { return a > b ? a : b; }
 template <typename R> __device__ __forceinline__ R kp_min(R a, R b) { return a < b ? a : b; }
 template <typename R> __device__ __forceinline__ R kp_clip(R x, R lo, R hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -237,8 +243,18 @@ __device__ __forceinline__ R wrap_to_pi(R v) {
 #pragma clang fp contract(off)
   const R PI = (R)3.141592653589793;
   const R TWO_PI = (R)2.0 * PI;
-  R m = kp_fmod(v + PI, TWO_PI);
-  if (m < (R)0) m += TWO_PI;
+  const R x = v + PI;
+  // Both angles of a pose difference are atan2 results, so x lies in [-pi, 3 pi]: there fmod is the identity, or ONE subtraction that is
+  // exact (Sterbenz: pi <= x <= 4 pi) -- the same bits as the library loop, without the loop.  Anything else (poses handed in through
+  // set_state / reset options) takes the general path.
+  R m;
+  if (x >= (R)0 && x < TWO_PI) m = x;
+  else if (x >= TWO_PI && x < (R)2 * TWO_PI) m = x - TWO_PI;
+  else if (x < (R)0 && x > -TWO_PI) m = x + TWO_PI;
+  else {
+    m = kp_fmod(x, TWO_PI);
+    if (m < (R)0) m += TWO_PI;
+  }
   return m - PI;
 }
 // KP1/kinematics/pose_utils.py:21-30: both error norms of curr vs goal
@@ -270,7 +286,7 @@ __device__ __forceinline__ R interpolate_control(R pos, R near_t, R far_t, R nea
   if (near_t <= (R)0 || far_t <= near_t) return fallback;
   if (pos <= near_t) return near_v;
   if (pos >= far_t) return far_v;
-  R alpha = (pos - near_t) / kp_max<R>(far_t - near_t, (R)1e-9);
+  R alpha = kp_div(pos - near_t, kp_max<R>(far_t - near_t, (R)1e-9));
   return near_v + alpha * (far_v - near_v);
 }
 
@@ -381,8 +397,8 @@ __device__ __forceinline__ R approach_reward(const typename DevCfg<R>::Reward& _
   if (nh_any) {
     R at = cfg.finisher_ready_action_threshold != Z ? cfg.finisher_ready_action_threshold : cfg.dock_coarse_ready_action_threshold;
     R dt = cfg.finisher_ready_dq_threshold != Z ? cfg.finisher_ready_dq_threshold : cfg.dock_coarse_ready_dq_threshold;
-    R action_clean = at > Z ? kp_max<R>((R)1 - an / kp_max<R>(at, (R)1e-9), Z) : Z;
-    R dq_clean = dt > Z ? kp_max<R>((R)1 - dqn / kp_max<R>(dt, (R)1e-9), Z) : Z;
+    R action_clean = at > Z ? kp_max<R>((R)1 - kp_div(an, kp_max<R>(at, (R)1e-9)), Z) : Z;
+    R dq_clean = dt > Z ? kp_max<R>((R)1 - kp_div(dqn, kp_max<R>(dt, (R)1e-9)), Z) : Z;
     nh_motion = cfg.near_handoff_motion_bonus_weight * ((R)0.5 * action_clean + (R)0.5 * dq_clean);
     nh_settle = cfg.near_handoff_settle_bonus_weight * ((R)0.5 * kp_max<R>(pan - an, Z) + (R)0.5 * kp_max<R>(pdqn - dqn, Z));
   }
@@ -421,7 +437,7 @@ __device__ __forceinline__ R entry_penalty_scale(R pos, R near_t, R far_t, R nea
   if (near_t <= (R)0 || far_t <= near_t) return (R)1;
   if (pos <= near_t) return near_m;
   if (pos >= far_t) return far_m;
-  R alpha = (pos - near_t) / kp_max<R>(far_t - near_t, (R)1e-9);
+  R alpha = kp_div(pos - near_t, kp_max<R>(far_t - near_t, (R)1e-9));
   return near_m + alpha * (far_m - near_m);
 }
 
@@ -447,25 +463,25 @@ __device__ __forceinline__ R dock_reward(const typename DevCfg<R>::DockReward& _
   bool curr_ns = curr_pos <= ns_pos_t && curr_ori <= ns_ori_t;
   bool prev_ns = prev_pos <= ns_pos_t && prev_ori <= ns_ori_t;
   R tp = kp_max<R>(cfg.tight_pose_pos_threshold_m, EPS), to = kp_max<R>(cfg.tight_pose_ori_threshold_rad, EPS);
-  R spc = kp_max<R>(ONE - curr_pos / tp, Z);
-  R soc = kp_max<R>(ONE - curr_ori / to, Z);
+  R spc = kp_max<R>(ONE - kp_div(curr_pos, tp), Z);
+  R soc = kp_max<R>(ONE - kp_div(curr_ori, to), Z);
   R sc_base = (R)0.8 * spc + (R)0.2 * soc;
   R strict_closeness = sc_base * sc_base;
   R tight_bonus = curr_tight ? cfg.tight_pose_bonus : Z;
   R tight_dwell = curr_tight ? cfg.tight_pose_dwell_bonus * (R)kp_maxi(dwell_count - 1, 0) : Z;
   R strict_leave = (prev_tight && !curr_tight) ? -cfg.strict_pose_leave_penalty : Z;
   R sc_reward = curr_tight ? cfg.strict_center_reward_weight * strict_closeness : Z;
-  R rp = curr_pos / tp, ro = curr_ori / to;
+  R rp = kp_div(curr_pos, tp), ro = kp_div(curr_ori, to);
   R sc_pos_pen = cfg.strict_center_position_weight > Z ? -cfg.strict_center_position_weight * (rp * rp) : Z;
   R sc_ori_pen = cfg.strict_center_orientation_weight > Z ? -cfg.strict_center_orientation_weight * (ro * ro) : Z;
   R action_rms = kp_sqrt(in.action_msq);
   R sc_small = Z;
   if (cfg.strict_center_small_action_bonus_weight > Z && cfg.strict_center_small_action_pos_radius_m > Z &&
       cfg.strict_center_small_action_ori_radius_rad > Z && cfg.strict_center_small_action_scale > Z && curr_tight) {
-    R cpc = kp_max<R>(ONE - curr_pos / cfg.strict_center_small_action_pos_radius_m, Z);
-    R coc = kp_max<R>(ONE - curr_ori / cfg.strict_center_small_action_ori_radius_rad, Z);
+    R cpc = kp_max<R>(ONE - kp_div(curr_pos, cfg.strict_center_small_action_pos_radius_m), Z);
+    R coc = kp_max<R>(ONE - kp_div(curr_ori, cfg.strict_center_small_action_ori_radius_rad), Z);
     R cc = kp_pow((R)0.8 * cpc + (R)0.2 * coc, cfg.strict_center_small_action_power);
-    R sm = kp_max<R>(ONE - action_rms / cfg.strict_center_small_action_scale, Z);
+    R sm = kp_max<R>(ONE - kp_div(action_rms, cfg.strict_center_small_action_scale), Z);
     sc_small = cfg.strict_center_small_action_bonus_weight * cc * sm;
   }
   R sc_dwell = Z;
@@ -475,9 +491,9 @@ __device__ __forceinline__ R dock_reward(const typename DevCfg<R>::DockReward& _
     sc_dwell = cfg.strict_center_dwell_bonus_weight * strict_closeness * scale;
   }
   R tps = cfg.tight_position_shaping_radius_m > Z
-              ? cfg.tight_position_shaping_weight * kp_max<R>(ONE - curr_pos / kp_max<R>(cfg.tight_position_shaping_radius_m, EPS), Z) : Z;
+              ? cfg.tight_position_shaping_weight * kp_max<R>(ONE - kp_div(curr_pos, kp_max<R>(cfg.tight_position_shaping_radius_m, EPS)), Z) : Z;
   R tos = cfg.tight_orientation_shaping_radius_rad > Z
-              ? cfg.tight_orientation_shaping_weight * kp_max<R>(ONE - curr_ori / kp_max<R>(cfg.tight_orientation_shaping_radius_rad, EPS), Z) : Z;
+              ? cfg.tight_orientation_shaping_weight * kp_max<R>(ONE - kp_div(curr_ori, kp_max<R>(cfg.tight_orientation_shaping_radius_rad, EPS)), Z) : Z;
   R conv_pos = (cfg.convergence_position_radius_m > Z && kp_min<R>(prev_pos, curr_pos) <= cfg.convergence_position_radius_m)
                    ? cfg.convergence_position_progress_weight * (prev_pos - curr_pos) : Z;
   R gate_scale = (cfg.position_first_orientation_pos_threshold_m > Z && curr_pos > cfg.position_first_orientation_pos_threshold_m)
@@ -542,9 +558,9 @@ __device__ __forceinline__ R dock_reward(const typename DevCfg<R>::DockReward& _
     bool p_o = prev_pos <= outer_r, p_i = prev_pos <= inner_r, p_d = prev_pos <= dwell_r;
     bool c_o = curr_pos <= outer_r, c_i = curr_pos <= inner_r, c_d = curr_pos <= dwell_r;
     zone = c_d ? 3 : (c_i ? 2 : (c_o ? 1 : 0));
-    if (c_o) b_outer = cfg.basin_outer_bonus * (ONE + kp_max<R>(ONE - curr_pos / outer_r, Z));
-    if (c_i) b_inner = cfg.basin_inner_bonus * (ONE + kp_max<R>(ONE - curr_pos / inner_r, Z));
-    if (c_d) b_dwell = cfg.basin_dwell_bonus * (ONE + kp_max<R>(ONE - curr_pos / dwell_r, Z));
+    if (c_o) b_outer = cfg.basin_outer_bonus * (ONE + kp_max<R>(ONE - kp_div(curr_pos, outer_r), Z));
+    if (c_i) b_inner = cfg.basin_inner_bonus * (ONE + kp_max<R>(ONE - kp_div(curr_pos, inner_r), Z));
+    if (c_d) b_dwell = cfg.basin_dwell_bonus * (ONE + kp_max<R>(ONE - kp_div(curr_pos, dwell_r), Z));
     b_outer_exit = (p_o && !c_o) ? -cfg.basin_outer_exit_penalty : Z;
     b_inner_exit = (p_i && !c_i) ? -cfg.basin_inner_exit_penalty : Z;
     b_dwell_break = (p_d && !c_d) ? -cfg.basin_dwell_break_penalty : Z;
@@ -588,14 +604,14 @@ __device__ __forceinline__ R joint_clip(R q, R lo, R hi) { return kp_clip<R>(q, 
 template <typename R>
 __device__ __forceinline__ R joint_limit_margin(R q, R lo, R hi) {
   const R span = joint_span<R>(lo, hi);
-  return kp_clip<R>((R)2 * kp_min<R>((q - lo) / span, (hi - q) / span), (R)0, (R)1);
+  return kp_clip<R>((R)2 * kp_min<R>(kp_div(q - lo, span), kp_div(hi - q, span)), (R)0, (R)1);
 }
 // normalize_joint_positions :153-158
 template <typename R>
-__device__ __forceinline__ R joint_normalize_q(R q, R lo, R hi) { return kp_clip<R>((R)2 * ((q - lo) / joint_span<R>(lo, hi)) - (R)1, (R)-1, (R)1); }
+__device__ __forceinline__ R joint_normalize_q(R q, R lo, R hi) { return kp_clip<R>((R)2 * kp_div(q - lo, joint_span<R>(lo, hi)) - (R)1, (R)-1, (R)1); }
 // normalize_joint_deltas :161-163
 template <typename R>
-__device__ __forceinline__ R joint_normalize_dq(R dq, R dlim) { return kp_clip<R>(dq / kp_max<R>(dlim, (R)1e-9), (R)-1, (R)1); }
+__device__ __forceinline__ R joint_normalize_dq(R dq, R dlim) { return kp_clip<R>(kp_div(dq, kp_max<R>(dlim, (R)1e-9)), (R)-1, (R)1); }
 
 // KP1/envs/observation_builder.py:29-94 -> one row of 56 floats in SB3 key order (kp1.h KP1_OBS_*)
 template <typename R>
@@ -612,13 +628,13 @@ __device__ __forceinline__ void build_observation(const DevCfg<R>& __restrict__ 
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    o[KP1_OBS_GOAL_POS_ERR + i] = (float)kp_clip<R>(pos_err[i] / c.obs.pos_err_scale_m, (R)-1, (R)1);
-    o[KP1_OBS_GOAL_ORI_ERR + i] = (float)kp_clip<R>(ori_err[i] / c.obs.ori_err_scale_rad, (R)-1, (R)1);
+    o[KP1_OBS_GOAL_POS_ERR + i] = (float)kp_clip<R>(kp_div(pos_err[i], c.obs.pos_err_scale_m), (R)-1, (R)1);
+    o[KP1_OBS_GOAL_ORI_ERR + i] = (float)kp_clip<R>(kp_div(ori_err[i], c.obs.ori_err_scale_rad), (R)-1, (R)1);
   }
   o[KP1_OBS_TASK_TYPE] = 1.0f;
   o[KP1_OBS_MODE_FLAG + (mode == KP1_MODE_APPROACH ? 0 : 1)] = 1.0f;
-  R ep = (R)episode_step / (R)kp_maxi(c.env.episode_length, 1);
-  R dp = (R)dwell_count / (R)kp_maxi(c.env.dwell_steps_target, 1);
+  R ep = kp_div((R)episode_step, (R)kp_maxi(c.env.episode_length, 1));
+  R dp = kp_div((R)dwell_count, (R)kp_maxi(c.env.dwell_steps_target, 1));
   o[KP1_OBS_PROGRESS + 0] = (float)kp_clip<R>(ep, (R)0, (R)1);
   o[KP1_OBS_PROGRESS + 1] = (float)kp_clip<R>(dp, (R)0, (R)1);
 }

@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
   RewardIn<R> ri;
   ri.prev_pos = prev_pos; ri.curr_pos = curr_pos; ri.prev_ori = prev_ori; ri.curr_ori = curr_ori;
   ri.action_norm = kp_sqrt(act_ss); ri.prev_action_norm = kp_sqrt(pact_ss);
-  ri.action_msq = act_ss / (R)7; ri.action_delta_msq = dact_ss / (R)7;
+  ri.action_msq = kp_div(act_ss, (R)7); ri.action_delta_msq = kp_div(dact_ss, (R)7);
   ri.dq_norm = kp_sqrt(dq_ss); ri.prev_dq_norm = kp_sqrt(prev_dq_ss); ri.dq_change_l2 = kp_sqrt(dq_change_ss);
   ri.margin_min = margin_min;
   ri.dwell = dwell; ri.entry_count = entry_count; ri.drift_count = drift_count;
