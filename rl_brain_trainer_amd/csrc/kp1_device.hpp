@@ -94,6 +94,119 @@ struct DevCfg {
   } kin;
 };
 
+// A wave-uniform, read-only block (DevCfg, DevSampler): route its loads through the constant address space, so that they are scalar loads
+// (SGPR operands, no vector registers, no vector-memory round trip) whatever the stores around them might alias.  Without this the
+// compiler falls back to uniform-address VECTOR loads for every config read it cannot prove unclobbered by the state stores.
+template <typename T>
+__device__ __forceinline__ const T& uniform_block(const T* p) {
+  typedef const __attribute__((address_space(4))) T* const_space_ptr;
+  return *(const T*)(const_space_ptr)p;
+}
+
+// The same block seen through a per-lane pointer (block + a zero the compiler cannot see through): its reads become VECTOR loads of a
+// wave-uniform address -- one cache line broadcast to all lanes -- with the SGPR-base + immediate-offset addressing form.  Why one would
+// want that for uniform data: scalar loads return out of order, so every use waits for ALL outstanding ones (s_waitcnt lgkmcnt(0)), and
+// 102 SGPRs hold only a few batches ahead; vector loads return in order (vmcnt(N) waits for exactly the one needed) and a wave that is
+// alone on its SIMD has 512 vector registers to prefetch into.
+template <typename T>
+__device__ __forceinline__ const T& lane_view(const T& block) {
+  uint32_t zero;
+  asm("v_mov_b32 %0, 0" : "=v"(zero));
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(&block) + zero);
+}
+
+// Warm the scalar data cache with a block the wave is about to read through scalar loads.  The step kernel reads ~400 scalars of DevCfg, and
+// the compiler (102 SGPRs) can only load them a few at a time next to their uses: each batch is then a dependent round trip to L2
+// (~200-500 cycles), and with ONE wave per SIMD nothing else runs meanwhile -- SQ_WAIT_ANY was 53 % of the wave's cycles
+// (profiles/r03_sq_counters.json).  One dword from every 64-byte line, all in flight at once, turns those round trips into scalar-cache
+// hits for the price of a single one.  Returns the block pointer made dependent on the loaded words (plus a run-time zero), so that every
+// later read of the block is ordered behind the warm-up without a volatile asm (a volatile asm counts as a store to everything for the
+// compiler, which then reads the whole block with uniform-address VECTOR loads).
+#ifndef KP1_CFG_WARM
+#define KP1_CFG_WARM 2
+#endif
+#define KP1_WARM_BYTES 4096   // blocks handed to scalar_cache_warm are allocated in multiples of this
+template <typename T>
+__device__ __forceinline__ const T* scalar_cache_warm(const T* __restrict__ block) {
+#if KP1_CFG_WARM == 2
+  // ONE asm statement: 64 loads (4 KB, the block's allocation is padded to that) into the same scratch SGPR -- the words are never used --,
+  // one wait, and the scratch register forced to zero as the statement's only output
+  static_assert(KP1_WARM_BYTES == 4096, "the load list below covers 4 KB");
+  uint32_t zero;
+  asm(
+      "s_load_dword %0, %1, 0x0\n\t"
+      "s_load_dword %0, %1, 0x40\n\t"
+      "s_load_dword %0, %1, 0x80\n\t"
+      "s_load_dword %0, %1, 0xc0\n\t"
+      "s_load_dword %0, %1, 0x100\n\t"
+      "s_load_dword %0, %1, 0x140\n\t"
+      "s_load_dword %0, %1, 0x180\n\t"
+      "s_load_dword %0, %1, 0x1c0\n\t"
+      "s_load_dword %0, %1, 0x200\n\t"
+      "s_load_dword %0, %1, 0x240\n\t"
+      "s_load_dword %0, %1, 0x280\n\t"
+      "s_load_dword %0, %1, 0x2c0\n\t"
+      "s_load_dword %0, %1, 0x300\n\t"
+      "s_load_dword %0, %1, 0x340\n\t"
+      "s_load_dword %0, %1, 0x380\n\t"
+      "s_load_dword %0, %1, 0x3c0\n\t"
+      "s_load_dword %0, %1, 0x400\n\t"
+      "s_load_dword %0, %1, 0x440\n\t"
+      "s_load_dword %0, %1, 0x480\n\t"
+      "s_load_dword %0, %1, 0x4c0\n\t"
+      "s_load_dword %0, %1, 0x500\n\t"
+      "s_load_dword %0, %1, 0x540\n\t"
+      "s_load_dword %0, %1, 0x580\n\t"
+      "s_load_dword %0, %1, 0x5c0\n\t"
+      "s_load_dword %0, %1, 0x600\n\t"
+      "s_load_dword %0, %1, 0x640\n\t"
+      "s_load_dword %0, %1, 0x680\n\t"
+      "s_load_dword %0, %1, 0x6c0\n\t"
+      "s_load_dword %0, %1, 0x700\n\t"
+      "s_load_dword %0, %1, 0x740\n\t"
+      "s_load_dword %0, %1, 0x780\n\t"
+      "s_load_dword %0, %1, 0x7c0\n\t"
+      "s_load_dword %0, %1, 0x800\n\t"
+      "s_load_dword %0, %1, 0x840\n\t"
+      "s_load_dword %0, %1, 0x880\n\t"
+      "s_load_dword %0, %1, 0x8c0\n\t"
+      "s_load_dword %0, %1, 0x900\n\t"
+      "s_load_dword %0, %1, 0x940\n\t"
+      "s_load_dword %0, %1, 0x980\n\t"
+      "s_load_dword %0, %1, 0x9c0\n\t"
+      "s_load_dword %0, %1, 0xa00\n\t"
+      "s_load_dword %0, %1, 0xa40\n\t"
+      "s_load_dword %0, %1, 0xa80\n\t"
+      "s_load_dword %0, %1, 0xac0\n\t"
+      "s_load_dword %0, %1, 0xb00\n\t"
+      "s_load_dword %0, %1, 0xb40\n\t"
+      "s_load_dword %0, %1, 0xb80\n\t"
+      "s_load_dword %0, %1, 0xbc0\n\t"
+      "s_load_dword %0, %1, 0xc00\n\t"
+      "s_load_dword %0, %1, 0xc40\n\t"
+      "s_load_dword %0, %1, 0xc80\n\t"
+      "s_load_dword %0, %1, 0xcc0\n\t"
+      "s_load_dword %0, %1, 0xd00\n\t"
+      "s_load_dword %0, %1, 0xd40\n\t"
+      "s_load_dword %0, %1, 0xd80\n\t"
+      "s_load_dword %0, %1, 0xdc0\n\t"
+      "s_load_dword %0, %1, 0xe00\n\t"
+      "s_load_dword %0, %1, 0xe40\n\t"
+      "s_load_dword %0, %1, 0xe80\n\t"
+      "s_load_dword %0, %1, 0xec0\n\t"
+      "s_load_dword %0, %1, 0xf00\n\t"
+      "s_load_dword %0, %1, 0xf40\n\t"
+      "s_load_dword %0, %1, 0xf80\n\t"
+      "s_load_dword %0, %1, 0xfc0\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_mov_b32 %0, 0"
+      : "=&s"(zero) : "s"(block));
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(block) + zero);
+#else
+  return block;
+#endif
+}
+
 // sampler configuration, always fp64 (reset path only)
 struct DevSampler {
   double lower[NJ], upper[NJ];
@@ -125,8 +238,15 @@ struct EnvState {
   uint64_t* rng64; // [4][N]: state_hi, state_lo, inc_hi, inc_lo
   uint32_t* rng32; // [2][N]: has_uint32, uinteger
   int64_t n;
-  __device__ __forceinline__ R& r(int f, int64_t i) const { return real[(int64_t)f * n + i]; }
-  __device__ __forceinline__ int32_t& iv(int f, int64_t i) const { return ints[(int64_t)f * n + i]; }
+  // Address of element i of field plane f = (wave-uniform plane base: scalar arithmetic) + (32-bit byte offset of the lane): the loads and
+  // stores take the SGPR-base addressing form, instead of a 64-bit multiply-add chain per field per lane (it was a tenth of the step's
+  // vector instructions).  kp1_create bounds n so that the byte offset fits 32 bits.
+  template <typename T>
+  static __device__ __forceinline__ T& at(T* plane, int64_t i) {
+    return plane[(uint32_t)i];
+  }
+  __device__ __forceinline__ R& r(int f, int64_t i) const { return at<R>(real + (int64_t)f * n, i); }
+  __device__ __forceinline__ int32_t& iv(int f, int64_t i) const { return at<int32_t>(ints + (int64_t)f * n, i); }
   // joint position as the kinematic chain carries it (fp64).  fp32 handle: a two-float value, 48 significant bits.
   __device__ __forceinline__ double q_load(int k, int64_t i) const {
     if constexpr (sizeof(R) == 4) return (double)r(F_Q + k, i) + (double)r(F_QLO + k, i);

@@ -28,6 +28,34 @@ using namespace kp1;
 // ============================================================================================
 namespace {
 
+// Developer timeline of the step kernel (tools/env_timeline.py builds a private copy with -DKP1_ENV_TRACE): lane 0 of every wave stamps the
+// shader clock (s_memtime) at the phase boundaries.  Compiled out of the product.
+#ifdef KP1_ENV_TRACE
+constexpr int KP1_ENV_TRACE_SLOTS = 16, KP1_ENV_TRACE_WAVES = 1024;
+__device__ unsigned long long kp1_env_trace_buf[KP1_ENV_TRACE_SLOTS * KP1_ENV_TRACE_WAVES];
+// KP1_ETR_PIN(slot, v...): the values a phase produces are made "used" right before the stamp, so that neither the optimiser nor the
+// scheduler can sink the phase's work below it
+__device__ __forceinline__ void etr_pin(float v) { asm volatile("" ::"v"(v)); }
+__device__ __forceinline__ void etr_pin(double v) { asm volatile("" ::"v"(v)); }
+__device__ __forceinline__ void etr_pin(int v) { asm volatile("" ::"v"(v)); }
+#define KP1_ETR_PIN(slot, ...)                                                                                                    \
+  {                                                                                                                               \
+    for (auto pv_ : {__VA_ARGS__}) etr_pin(pv_);                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                            \
+    KP1_ETR(slot)                                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                                            \
+  }
+#define KP1_ETR(slot)                                                                                                             \
+  {                                                                                                                               \
+    const unsigned long long t_ = __builtin_readcyclecounter();                                                                   \
+    const int w_ = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);                                                           \
+    if ((threadIdx.x & 63) == 0 && w_ < KP1_ENV_TRACE_WAVES) kp1_env_trace_buf[w_ * KP1_ENV_TRACE_SLOTS + (slot)] = t_;           \
+  }
+#else
+#define KP1_ETR(slot)
+#define KP1_ETR_PIN(slot, ...)
+#endif
+
 constexpr int OPT_INITIAL_Q = 1, OPT_INITIAL_DQ = 2, OPT_INITIAL_PREV_ACTION = 4, OPT_GOAL_Q = 8, OPT_GOAL_POSE6 = 16;
 
 struct ResetOptsDev {
@@ -40,16 +68,20 @@ struct ResetOptsDev {
 };
 
 __device__ __forceinline__ void rng_load(const uint64_t* __restrict__ r64, const uint32_t* __restrict__ r32, int64_t n, int64_t i, Pcg& r) {
-  r.state = ((unsigned __int128)r64[0 * n + i] << 64) | r64[1 * n + i];
-  r.inc = ((unsigned __int128)r64[2 * n + i] << 64) | r64[3 * n + i];
-  r.has_uint32 = r32[0 * n + i];
-  r.uinteger = r32[1 * n + i];
+  const uint32_t o8 = (uint32_t)i * 8u, o4 = (uint32_t)i * 4u;   // plane base (uniform) + 32-bit lane offset, as EnvState::at
+  auto w64 = [&](int plane) { return *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(r64 + plane * n) + o8); };
+  auto w32 = [&](int plane) { return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(r32 + plane * n) + o4); };
+  r.state = ((unsigned __int128)w64(0) << 64) | w64(1);
+  r.inc = ((unsigned __int128)w64(2) << 64) | w64(3);
+  r.has_uint32 = w32(0);
+  r.uinteger = w32(1);
 }
 __device__ __forceinline__ void rng_store(uint64_t* __restrict__ r64, uint32_t* __restrict__ r32, int64_t n, int64_t i, const Pcg& r) {
-  r64[0 * n + i] = (uint64_t)(r.state >> 64);
-  r64[1 * n + i] = (uint64_t)r.state;
-  r32[0 * n + i] = r.has_uint32;
-  r32[1 * n + i] = r.uinteger;
+  const uint32_t o8 = (uint32_t)i * 8u, o4 = (uint32_t)i * 4u;
+  *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(r64 + 0 * n) + o8) = (uint64_t)(r.state >> 64);
+  *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(r64 + 1 * n) + o8) = (uint64_t)r.state;
+  *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(r32 + 0 * n) + o4) = r.has_uint32;
+  *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(r32 + 1 * n) + o4) = r.uinteger;
 }
 
 // one observation row = 14 float4 stores (+2 zero float4 when the row pitch is the MFMA-friendly 64)
@@ -270,7 +302,21 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n = a.st.n;
   if (i >= n) return;
-  const DevCfg<R>& __restrict__ cfg = *a.cfg;
+  KP1_ETR(0)
+#ifndef KP1_CFG_VEC
+#define KP1_CFG_VEC 0     // 0: config through scalar loads; 1: the FK constants through lane_view; 2: the whole block through lane_view
+#endif
+#if KP1_CFG_VEC == 2
+  const DevCfg<R>& __restrict__ cfg = lane_view(*a.cfg);
+  const DevFk<double>& __restrict__ fkc = cfg.kin.fk;
+#elif KP1_CFG_VEC == 1
+  const DevCfg<R>& __restrict__ cfg = *scalar_cache_warm(a.cfg);
+  const DevFk<double>& __restrict__ fkc = lane_view(cfg.kin.fk);
+#else
+  const DevCfg<R>& __restrict__ cfg = *scalar_cache_warm(a.cfg);
+  const DevFk<double>& __restrict__ fkc = cfg.kin.fk;
+#endif
+  KP1_ETR(1)
   const EnvState<R>& st = a.st;
   const R Z = (R)0;
 
@@ -294,6 +340,7 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
 
   R pe[3], oe[3], prev_pos, prev_ori;
   pose_error_norms<R>(ee, goal, pe, oe, &prev_pos, &prev_ori);  // :219-221
+  KP1_ETR_PIN(2, prev_pos, prev_ori)
 
   R dyn_limit = kp_clip<R>(cfg.env.dock_residual_action_limit, Z, (R)1);
   R dyn_dqc = kp_max<R>(cfg.env.dock_delta_q_change_limit_scale, Z);
@@ -349,8 +396,10 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
     dact_ss += da * da;
     margin_min = kp_min<R>(margin_min, joint_limit_margin<R>(q_next[k], cfg.lower[k], cfg.upper[k]));  // joint_limits.py:166-174
   }
+  KP1_ETR_PIN(3, q_next64[0], q_next64[1], q_next64[2], q_next64[3], q_next64[4], q_next64[5], q_next64[6], (double)margin_min, (double)dq_change_ss)
   R ee_next[6];
-  fk_pose6_kin<R>(cfg.kin.fk, q_next64, ee_next);  // :246
+  fk_pose6_kin<R>(fkc, q_next64, ee_next);  // :246
+  KP1_ETR_PIN(4, ee_next[0], ee_next[1], ee_next[2], ee_next[3], ee_next[4], ee_next[5])
   R curr_pos, curr_ori;
   pose_error_norms<R>(ee_next, goal, pe, oe, &curr_pos, &curr_ori);  // :248-250
   const bool curr_pre = is_pre_near_goal<R>(cfg, curr_pos, curr_ori);
@@ -376,6 +425,7 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
   }
   if (!terminated && step_count >= cfg.term.max_episode_steps) truncated = true;
 
+  KP1_ETR_PIN(5, curr_pos, curr_ori, (R)dwell, (R)(terminated ? 1 : 0), (R)(truncated ? 1 : 0))
   RewardIn<R> ri;
   ri.prev_pos = prev_pos; ri.curr_pos = curr_pos; ri.prev_ori = prev_ori; ri.curr_ori = curr_ori;
   ri.action_norm = kp_sqrt(act_ss); ri.prev_action_norm = kp_sqrt(pact_ss);
@@ -393,12 +443,14 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
     ri.entry_pos = ri.entry_ori = ri.entry_action = ri.entry_dq = Z;
     reward = approach_reward<R, COMPS>(cfg.reward, ri, COMPS ? a.comps + i : nullptr, n);
   }
+  KP1_ETR_PIN(6, reward)
   episode_step += 1;  // :344
   if (curr_near) flags |= FLAG_NEAR_HIT;
   flags = success ? (flags | FLAG_SUCCESS) : (flags & ~FLAG_SUCCESS);
 
   float o[KP1_OBS_DIM];
   build_observation<R>(cfg, MODE, q_next, dq_next, act, pe, oe, episode_step, dwell, o);
+  KP1_ETR_PIN(7, o[0], o[7], o[14], o[21], o[28], o[31], o[34], o[40], o[54], o[55], o[6], o[13], o[20], o[27])
   a.reward[i] = reward;
   const bool done = terminated || truncated;
   a.done[i] = (uint8_t)((terminated ? KP1_DONE_TERMINATED : 0) | (truncated ? KP1_DONE_TRUNCATED : 0) |
@@ -408,8 +460,9 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
     if (a.terminal_obs) store_obs_row(a.terminal_obs, i, o, a.obs_stride);
     ResetOptsDev none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     int stage = a.stage_index;
-    if (a.stage_ptr) stage = kp_clipi(*a.stage_ptr, 0, kp_maxi(a.smp->n_stages - 1, 0));
-    reset_env<R, MODE>(st, cfg, *a.smp, a.handoff, none, stage, i, o);
+    const DevSampler& smp = uniform_block(a.smp);
+    if (a.stage_ptr) stage = kp_clipi(*a.stage_ptr, 0, kp_maxi(smp.n_stages - 1, 0));
+    reset_env<R, MODE>(st, cfg, smp, a.handoff, none, stage, i, o);
     // info of the finished episode stays readable (SB3 infos[i] of a done env is the terminal info)
     st.r(F_POS_ERR, i) = curr_pos;
     st.r(F_ORI_ERR, i) = curr_ori;
@@ -439,6 +492,11 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
     st.iv(I_FLAGS, i) = flags;
   }
   store_obs_row(a.obs, i, o, a.obs_stride);
+  KP1_ETR(8)
+#ifdef KP1_ENV_TRACE
+  __builtin_amdgcn_s_waitcnt(0);   // every store of this wave acknowledged
+  KP1_ETR(9)
+#endif
 }
 
 template <typename R, int MODE>
@@ -448,7 +506,7 @@ __global__ void __launch_bounds__(256) kp1_reset_kernel(const EnvState<R> st, co
   if (i >= st.n) return;
   if (mask && !mask[i]) return;
   float o[KP1_OBS_DIM];
-  reset_env<R, MODE>(st, *cfg, *smp, handoff, opts, stage_index, i, o);
+  reset_env<R, MODE>(st, uniform_block(cfg), uniform_block(smp), handoff, opts, stage_index, i, o);
   if (obs) store_obs_row(obs, i, o, obs_stride);
 }
 
@@ -825,6 +883,7 @@ struct kp1_env {
   DevSampler* dev_smp = nullptr;
   kp1_handoff_state* dev_handoff = nullptr;
   int32_t n_handoff = 0;
+  kp1_dock_curriculum_state* dock_tracker = nullptr;   // device tracker attached by kp1_dock_curriculum_create (its stage survives upload_cfg)
   double* opt_scratch = nullptr;  // 4*[N][7] + [N][6] doubles for explicit reset options / set_state
   const int32_t* stage_ptr = nullptr;  // kp1_bind_stage_ptr
   int32_t obs_stride = KP1_OBS_DIM;    // kp1_set_obs_stride
@@ -848,6 +907,8 @@ EnvState<R> state_of(const kp1_env* e) {
   return st;
 }
 
+int reapply_dock_stage(kp1_env* env);   // kp1_dock_curriculum.inc
+
 int upload_cfg(kp1_env* e) {
   if (e->real_type == KP1_REAL_F64) {
     DevCfg<double> d;
@@ -862,7 +923,7 @@ int upload_cfg(kp1_env* e) {
   make_dev_sampler(e->cfg, e->n_handoff, &s);
   HIP_TRY(hipMemcpyAsync(e->dev_smp, &s, sizeof s, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));  // d / s are stack objects
-  return KP1_OK;
+  return reapply_dock_stage(e);
 }
 
 int seed_streams(kp1_env* e, uint64_t seed0, uint64_t first_env_id) {
@@ -1034,6 +1095,7 @@ int kp1_create(const kp1_config* cfg, int32_t n_envs, int32_t device, int32_t re
                void* stream, kp1_env** out) {
   if (!cfg || !out) return fail(KP1_ERR_INVALID, "cfg/out is NULL");
   if (n_envs <= 0) return fail(KP1_ERR_INVALID, "n_envs must be positive");
+  if (n_envs > (1 << 28)) return fail(KP1_ERR_INVALID, "n_envs above 2^28: a lane's byte offset inside a state plane must fit 32 bits");
   if (real_type != KP1_REAL_F32 && real_type != KP1_REAL_F64) return fail(KP1_ERR_INVALID, "real_type must be KP1_REAL_F32 or KP1_REAL_F64");
   if (cfg->env.mode != KP1_MODE_APPROACH && cfg->env.mode != KP1_MODE_DOCK) return fail(KP1_ERR_UNSUPPORTED, "mode must be approach or dock");
   if (cfg->n_stages < 0 || cfg->n_stages > KP1_MAX_STAGES) return fail(KP1_ERR_INVALID, "n_stages out of range");
@@ -1063,7 +1125,7 @@ int kp1_create(const kp1_config* cfg, int32_t n_envs, int32_t device, int32_t re
   KP1_ALLOC(e->ints, sizeof(int32_t) * I_NUM_INT * n);
   KP1_ALLOC(e->rng64, sizeof(uint64_t) * 4 * n);
   KP1_ALLOC(e->rng32, sizeof(uint32_t) * 2 * n);
-  KP1_ALLOC(e->dev_cfg, real_type == KP1_REAL_F64 ? sizeof(DevCfg<double>) : sizeof(DevCfg<float>));
+  KP1_ALLOC(e->dev_cfg, ((real_type == KP1_REAL_F64 ? sizeof(DevCfg<double>) : sizeof(DevCfg<float>)) + KP1_WARM_BYTES - 1) / KP1_WARM_BYTES * KP1_WARM_BYTES);
   KP1_ALLOC(e->dev_smp, sizeof(DevSampler));
 #undef KP1_ALLOC
   int rc = upload_cfg(e);
@@ -1415,6 +1477,18 @@ int kp1_rng_set(kp1_env* e, const kp1_rng_state* in) {
   HIP_TRY(hipStreamSynchronize(e->stream));
   return KP1_OK;
 }
+
+#ifdef KP1_ENV_TRACE
+int kp1_debug_env_trace(unsigned long long* out, int clear) {
+  HIP_TRY(hipDeviceSynchronize());
+  if (out) HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(kp1_env_trace_buf), sizeof(unsigned long long) * KP1_ENV_TRACE_SLOTS * KP1_ENV_TRACE_WAVES));
+  if (clear) {
+    std::vector<unsigned long long> z(KP1_ENV_TRACE_SLOTS * KP1_ENV_TRACE_WAVES, 0ull);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(kp1_env_trace_buf), z.data(), sizeof(unsigned long long) * z.size()));
+  }
+  return KP1_OK;
+}
+#endif
 
 int kp1_fk_pose6(int32_t device, int32_t real_type, const void* q_dev, void* pose6_dev, int64_t n, void* stream) {
   if (!q_dev || !pose6_dev || n < 0) return fail(KP1_ERR_INVALID, "bad argument");

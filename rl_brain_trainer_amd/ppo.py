@@ -145,14 +145,76 @@ def gaussian_log_prob(actions: torch.Tensor, mean: torch.Tensor, log_std: torch.
     return (-0.5 * z * z - log_std - LOG_SQRT_2PI).sum(-1)
 
 
+class GraphSegments:
+    """A launch sequence captured as a CHAIN of hipGraphs with eager calls between them (the data-parallel collectives when they are not
+    captured themselves).  During capture `cut(fn)` ends the running segment, records `fn` and opens the next one; `replay()` walks the
+    chain in capture order on the current stream.  All segments share one memory pool (tensors allocated inside one segment and read by a
+    later one, or by a recorded call, keep their addresses; replaying strictly in capture order is what makes sharing the pool safe).
+    `on_begin` runs inside every freshly opened capture (the env re-reads the capture stream there)."""
+
+    def __init__(self, device: torch.device, on_begin=None) -> None:
+        self.device = device
+        self.plan: list[Any] = []
+        self.n_graphs = 0
+        self._pool = torch.cuda.graph_pool_handle()
+        self._on_begin = on_begin
+        self._cur = None
+
+    def begin(self) -> None:
+        g = torch.cuda.CUDAGraph()
+        ctx = torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local")
+        ctx.__enter__()
+        self._cur = (g, ctx)
+        if self._on_begin is not None:
+            self._on_begin()
+
+    def _end(self) -> None:
+        g, ctx = self._cur
+        self._cur = None
+        ctx.__exit__(None, None, None)
+        self.plan.append(g)
+        self.n_graphs += 1
+
+    def cut(self, fn) -> None:
+        self._end()
+        self.plan.append(fn)
+        self.begin()
+
+    def finish(self) -> None:
+        self._end()
+
+    def abort(self) -> None:
+        if self._cur is not None:
+            g, ctx = self._cur
+            self._cur = None
+            try:
+                ctx.__exit__(None, None, None)
+            except Exception:  # noqa: BLE001 -- already unwinding from the error that made the capture fail
+                pass
+
+    def replay(self) -> None:
+        for item in self.plan:
+            if isinstance(item, torch.cuda.CUDAGraph):
+                item.replay()
+            else:
+                item()
+
+
 class Dist:
     """torch.distributed glue (backend nccl = RCCL on ROCm, gloo on CPU tests).  world_size 1 = no-ops.
 
-    RCCL collectives are captured INSIDE the hipGraphs of the rollout and of the update epoch (``graphs_ok``): with ~100 us of
-    kernels per optimiser step an eagerly launched 650 KB all-reduce would leave the GPU idle for its whole host latency 512 times per
-    iteration.  Whether capture works is probed once per process on a 4-float all-reduce and a 16-byte all-gather (capture, replay, check the results); any exception
-    or wrong result selects the eager path on ALL ranks (the verdict is itself all-reduced), a hang is turned into a clear process exit
-    by a watchdog.  ``KP1_DIST_GRAPHS=0`` skips the probe and runs eagerly."""
+    How the collectives meet the hipGraphs of the rollout and of the update epoch (``graph_mode``):
+
+    * ``"segmented"`` (the default for world_size > 1): the compute between two collectives is captured as one hipGraph segment
+      (GraphSegments) and the collectives are launched eagerly between the replays, on the same stream.  Needs nothing from the backend
+      (works with gloo), keeps every kernel sequence out of the host's launch path, and costs two graph launches + one collective enqueue
+      per optimiser step (~40 us of host time against ~85 us of kernels: the host stays ahead).
+    * ``"captured"`` (opt-in, ``KP1_DIST_GRAPHS=1``, nccl only): the RCCL collectives are captured INSIDE the graphs.  No multi-GPU run of
+      this path has been recorded yet (the builder has one GPU), so it is not the default; when selected it is probed once per process
+      (capture + replay + check of a 4-float all-reduce and a 16-byte all-gather, the verdict all-reduced so every rank takes the same
+      path) and a watchdog turns a hang of the probe, of the first real rollout replay or of the first real epoch replay into a process
+      exit with a message (never a re-exec); PPO additionally checks after those first replays that all ranks hold identical parameters.
+    * single process: plain captured graphs."""
 
     def __init__(self) -> None:
         import torch.distributed as dist
@@ -163,10 +225,17 @@ class Dist:
         self.rank = dist.get_rank() if self.enabled else 0
         self.backend = str(dist.get_backend()) if self.enabled else ""
         self._graphs_ok: bool | None = None
+        self._segments: GraphSegments | None = None     # set while a segmented capture records: collectives become cut points
+
+    def _collective(self, fn) -> None:
+        if self._segments is not None:
+            self._segments.cut(fn)
+        else:
+            fn()
 
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         if self.enabled:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            self._collective(lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM))
         return t
 
     def all_gather_bytes(self, t: torch.Tensor) -> torch.Tensor:
@@ -179,7 +248,8 @@ class Dist:
     def all_gather_into(self, out: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
         """out[world, ...] <- every rank's t (rank-major), into a caller-owned buffer (graph replays need a fixed address)."""
         if self.enabled:
-            self.dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1))
+            dst, src = out.view(-1), t.contiguous().view(-1)
+            self._collective(lambda: self.dist.all_gather_into_tensor(dst, src))
         else:
             out.view(-1).copy_(t.reshape(-1))
         return out
@@ -197,12 +267,43 @@ class Dist:
             self._graphs_ok = self._probe_graph_collectives(device)
         return self._graphs_ok
 
+    def graph_mode(self, device: torch.device) -> str:
+        """"captured" (collectives inside the graphs; always so for a single process) or "segmented" (graph segments, eager collectives)"""
+        return "captured" if self.graphs_ok(device) else "segmented"
+
+    def watchdog(self, seconds: float, what: str):
+        """arm a timer that ends the process (exit code 3, a message, no re-exec) if `what` has not finished; returns the timer to cancel"""
+        import os
+        import sys
+        import threading
+
+        def _hung() -> None:
+            print(f"[kp1] {what} did not complete within {seconds:.0f} s: re-run with KP1_DIST_GRAPHS=0 (segmented graphs, eager collectives)",
+                  file=sys.stderr, flush=True)
+            os._exit(3)
+
+        dog = threading.Timer(seconds, _hung)
+        dog.daemon = True
+        dog.start()
+        return dog
+
+    def ranks_agree(self, flat: torch.Tensor) -> bool:
+        """every rank holds bit-identical `flat` (digest min == max over ranks); a collective itself, call it on all ranks"""
+        if not self.enabled:
+            return True
+        d = flat.double()
+        digest = torch.stack([d.sum(), d.abs().sum(), d[::97].sum()])
+        lo, hi = digest.clone(), digest.clone()
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN)
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX)
+        return bool(torch.equal(lo, hi)) and bool(torch.isfinite(digest).all())
+
     def _probe_graph_collectives(self, device: torch.device) -> bool:
         import os
         import sys
         import threading
 
-        ok = self.backend == "nccl" and os.environ.get("KP1_DIST_GRAPHS", "1") != "0"
+        ok = self.backend == "nccl" and os.environ.get("KP1_DIST_GRAPHS", "0") == "1"   # opt-in: see the class docstring
         verdict = torch.tensor([1.0 if ok else 0.0], device=device)
         if ok:
             buf = torch.full((4,), float(self.rank + 1), device=device)
@@ -305,9 +406,12 @@ class PPO:
             self.noise = torch.zeros((N, ACT_DIM), dtype=torch.float32, device=dev)
         elif backend != "torch":
             raise ValueError("backend must be 'hip' or 'torch'")
-        # hipGraph replay of the rollout (T x 3 launches) and of one update epoch.  Data parallel: the RCCL collectives are captured inside
-        # the graphs when the process group allows it (Dist.graphs_ok), else every launch is eager.
-        self.use_graphs = bool(use_graphs and backend == "hip" and self.dist.graphs_ok(self.device))
+        # hipGraph replay of the rollout (T x 3 launches) and of one update epoch.  Data parallel: graph segments with eager collectives
+        # between them, or (opt-in) the RCCL collectives captured inside the graphs: Dist.graph_mode.
+        self.use_graphs = bool(use_graphs and backend == "hip")
+        self.graph_mode = self.dist.graph_mode(self.device) if self.use_graphs else "none"
+        self._first_replay_checked = {"rollout": not (self.dist.enabled and self.graph_mode == "captured"),
+                                      "epoch": not (self.dist.enabled and self.graph_mode == "captured")}
         self._rollout_graph = None
         self._epoch_graph = None
         self._rollout_graph_key = None     # (env.launch_args_version, curriculum attached?) the rollout graph was captured with
@@ -324,8 +428,11 @@ class PPO:
         # optional host hook after every env step (done bits of that step, device tensor): what SB3 callbacks' _on_step sees.
         # Setting it makes the rollout eager (a host hook cannot live inside a hipGraph replay).
         self.step_callback = None
-        if self.use_graphs:
+        if backend == "hip":
+            # exploration noise of a whole rollout is drawn in ONE call, graphs or not: the eager and the replayed rollout then consume the
+            # generator identically and stay bit-identical (tests/test_distributed_gpu.py compares them)
             self.noise_all = torch.zeros((T, N, ACT_DIM), dtype=torch.float32, device=dev)
+        if self.use_graphs:
             self.perm = torch.zeros(T * N, dtype=torch.int64, device=dev)
 
     # Minibatch shuffles.  At the benchmarked size (524288 samples) a sort-based torch.randperm is 0.16 ms of full-chip kernels, eight times per
@@ -495,18 +602,18 @@ class PPO:
         std = torch.exp(log_std)
         world = self.dist.world_size
         graph_rollout = self.use_graphs and self.step_callback is None
-        if graph_rollout:
+        if self._mlp is not None:
             self.noise_all.normal_(generator=self.gen)
+        if graph_rollout:
             key = (getattr(env, "launch_args_version", 0), self.curriculum is not None, cfg.gamma, cfg.gae_lambda)   # what a capture freezes
             if self._rollout_graph is None or self._rollout_graph_key != key:
                 self._capture_rollout()
                 self._rollout_graph_key = key
-            self._rollout_graph.replay()
+            self._replay_checked("rollout", self._rollout_graph)
         for t in range(0 if not graph_rollout else T, T):
             if self._mlp is not None:
                 # 3 launches: two MFMA layer GEMMs + the head kernel (heads, sampling, log-prob, clip fused)
-                self.noise.normal_(generator=self.gen)
-                self._mlp.forward(self.obs_buf[t], noise=self.noise, value=self.val_buf[t], action=self.act_buf[t],
+                self._mlp.forward(self.obs_buf[t], noise=self.noise_all[t], value=self.val_buf[t], action=self.act_buf[t],
                                   clipped=self.clip_act, log_prob=self.logp_buf[t])
             else:
                 mean, value = self._forward(self.obs_buf[t])
@@ -577,26 +684,65 @@ class PPO:
             torch.cuda.current_stream(self.device).wait_stream(side)
             self._kernels_warm = True
         torch.cuda.synchronize(self.device)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local" if self.dist.enabled else "global"):
-            self.env.use_current_stream()
+
+        def body() -> None:
             for t in range(T):
                 self._rollout_step_hip(t)
             self._post_rollout()
+
+        self._rollout_graph = self._capture(body, on_begin=self.env.use_current_stream)
         self.env.use_current_stream()
-        self._rollout_graph = g
 
     def _capture_epoch(self, obs, act, old_logp, adv, ret, total: int, local_bs: int) -> None:
         """one update epoch = advantage statistics of all minibatches (+ ONE all-reduce of them), then per minibatch: tile kernel, weight
         gradients, finalize, [flat gradient all-reduce, sum of squares], Adam -- captured with the collectives inside"""
-        g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(self.device)
-        with torch.cuda.graph(g, capture_error_mode="thread_local" if self.dist.enabled else "global"):
+
+        def body() -> None:
             mb_stats = self._epoch_adv_stats(adv, self.perm, total, local_bs)
             for i, start in enumerate(range(0, total, local_bs)):
                 self._hip_minibatch_step(obs, self.perm[start:start + local_bs], act, old_logp, adv, ret, device_step=True,
                                          adv_stats=None if mb_stats is None else mb_stats[i])
-        self._epoch_graph = g
+
+        self._epoch_graph = self._capture(body)
+
+    def _capture(self, body, on_begin=None):
+        """record `body` once: ONE hipGraph (single process, or collectives captured inside), or a GraphSegments chain cut at every collective"""
+        if self.dist.enabled and self.graph_mode == "segmented":
+            seg = GraphSegments(self.device, on_begin=on_begin)
+            self.dist._segments = seg
+            try:
+                seg.begin()
+                body()
+                seg.finish()
+            except BaseException:
+                seg.abort()
+                raise
+            finally:
+                self.dist._segments = None
+            return seg
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local" if self.dist.enabled else "global"):
+            if on_begin is not None:
+                on_begin()
+            body()
+        return g
+
+    def _replay_checked(self, what: str, graph) -> None:
+        """replay; the FIRST replay of a graph that has RCCL collectives captured inside runs under a watchdog and is followed by a check
+        that every rank still holds the same parameters (that path has no recorded multi-GPU run: a hang or a divergence must end the job
+        with a message instead of a silent wrong result)"""
+        if self._first_replay_checked[what]:
+            graph.replay()
+            return
+        dog = self.dist.watchdog(300.0, f"the first replay of the {what} graph with captured RCCL collectives")
+        graph.replay()
+        torch.cuda.synchronize(self.device)
+        ok = self.dist.ranks_agree(self.policy.flat)
+        dog.cancel()
+        self._first_replay_checked[what] = True
+        if not ok:
+            raise RuntimeError(f"ranks diverged after the first replay of the {what} graph with captured RCCL collectives; re-run with KP1_DIST_GRAPHS=0")
 
     # ------------------------------------------------------------------ update
     def train(self) -> None:
@@ -633,7 +779,7 @@ class PPO:
                         continue
                     self._capture_epoch(obs, act, old_logp, adv, ret, total, local_bs)
                     self._epoch_graph_key = self._epoch_key()
-                self._epoch_graph.replay()
+                self._replay_checked("epoch", self._epoch_graph)
                 n_updates += (total + local_bs - 1) // local_bs
                 self.adam_t += (total + local_bs - 1) // local_bs
                 continue

@@ -40,7 +40,9 @@ def test_bench_gpus2_spawns_two_ranks():
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert two["scaling"] == "weak" and two["config"]["ranks_in_sync"] is True
     assert two["config"]["backend"] == "gloo" and two["config"]["done_exchange_steps"] == 16
-    assert two["config"]["collectives_in_graph"] is False          # gloo cannot be captured: the eager fallback ran
+    # gloo cannot be captured: the compute segments are hipGraphs, the collectives run eagerly between them
+    assert two["config"]["collectives_in_graph"] is False and two["config"]["graph_mode"] == "segmented" and two["config"]["hip_graphs"] is True
+    assert one["config"]["graph_mode"] == "captured" and one["config"]["hip_graphs"] is True
     # weak-scaling bookkeeping, as an identity over fields the line itself prints (no ratio of two wall clocks: two gloo ranks on one card
     # measure the box's host all-reduce latency, not the engine): value = steps * n_steps * envs/GPU * world / (max-over-ranks seconds)
     for rec in (one, two):

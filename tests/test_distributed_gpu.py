@@ -41,7 +41,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         env.set_curriculum_stage(5)
         pcfg = P.PPOConfig(n_steps=T, batch_size=1024 * world, n_epochs=1, hidden=256, learning_rate=1e-3, seed=806, clip_range=0.1, ent_coef=3e-4)
         ppo = P.PPO(env, pcfg, dist=P.Dist(), backend="hip")
-        assert ppo.dist.enabled and not ppo.use_graphs
+        assert ppo.dist.enabled and ppo.use_graphs and ppo.graph_mode == "segmented"     # gloo: graph segments, eager collectives
         ppo.collect_rollouts()
         total = T * N
         obs = ppo.obs_buf[:T].view(total, ppo.obs_w)
@@ -97,6 +97,60 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         env.close()
     finally:
         dist.destroy_process_group()
+
+
+def _segmented_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    """the same two-iteration training run twice in one process: hipGraph segments with eager collectives between them, then every launch
+    eager.  Both must leave bit-identical parameters, Adam moments, rollout buffers and curriculum tracker state on every rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import load_golden_config
+        from rl_brain_trainer_amd import ppo as P
+        from rl_brain_trainer_amd.curriculum import PointCurriculum
+        from rl_brain_trainer_amd.vec_env import ArmKinematicVecEnv
+
+        cfg = load_golden_config("workspace_expansion_bigtrain")
+        N, T = 192, 32
+
+        def run(use_graphs: bool):
+            env = ArmKinematicVecEnv(cfg, N, seed=806, first_env_id=rank * N)
+            cur = PointCurriculum(success_rate_threshold=0.0, window_episodes=8, min_episodes_per_stage=16, max_stage_index=11, initial_stage_index=2)
+            pcfg = P.PPOConfig(n_steps=T, batch_size=1024 * world, n_epochs=3, hidden=256, learning_rate=1e-3, seed=806, clip_range=0.1, ent_coef=3e-4)
+            ppo = P.PPO(env, pcfg, curriculum=cur, dist=P.Dist(), backend="hip", use_graphs=use_graphs)
+            for _ in range(3):          # iteration 1 captures (rollout at once, the epoch after one eager epoch), 2 and 3 replay
+                ppo.collect_rollouts()
+                ppo.train()
+            torch.cuda.synchronize()
+            st = cur.read()
+            out = (ppo.policy.flat.clone(), ppo.adam_m.clone(), ppo.adam_v.clone(), ppo.adv_buf.clone(), ppo.obs_buf.clone(),
+                   (st.stage_index, st.stage_episode_count, st.ring_len, st.ring_head, st.n_events, st.num_timesteps), ppo.graph_mode,
+                   None if not use_graphs else (ppo._rollout_graph.n_graphs, ppo._epoch_graph.n_graphs))
+            cur.close()
+            env.close()
+            return out
+
+        seg, eager = run(True), run(False)
+        assert seg[6] == "segmented" and eager[6] == "none"
+        # rollout: one segment per done-exchange chunk + the tail; epoch: advantage sums | stats + first tile ... | last Adam
+        assert seg[7][0] == T // 16 + 1 and seg[7][1] == (T * N) // 1024 + 2, seg[7]
+        for a, b in zip(seg[:5], eager[:5]):
+            assert torch.equal(a, b)
+        assert seg[5] == eager[5] and seg[5][0] > 2 and seg[5][5] == 3 * T * N * world       # the tracker promoted, on global timesteps
+        both = [None] * world
+        dist.all_gather_object(both, seg[0].cpu().numpy())
+        assert np.array_equal(both[0], both[1])
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_segmented_graphs_match_eager(tmp_path):
+    world = 2
+    mp.spawn(_segmented_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
 def test_two_rank_hip_data_parallel_update(tmp_path):
