@@ -494,7 +494,9 @@ typedef struct kp1_eval_buffers {
   int32_t* counters;      /* [4][n]: step_count, max_ready_streak, first_ready_step (-1 = never), current streak */
   uint8_t* flags;         /* [4][n]: alive, success, ready_hit, handoff taken */
   double* state;          /* [n][34]: q 7, dq 7, prev_action 7, goal_q 7, goal_pose6 6 of the last step the episode was alive */
-  double* hand_metrics;   /* [6][n]: pos, ori, |action|, |dq|, min pos, min ori at the handoff step (NULL when handoff_confirm_steps == 0) */
+  double* hand_metrics;   /* [8][n]: pos, ori, |action|, |dq|, min pos, min ori, sum |action|, sum |dq| at the handoff step; NULL = no handoff
+                             snapshot wanted (_run_policy).  Given: snapshot at the first step with ready_streak >= handoff_confirm_steps
+                             (eval_pipeline_ablation.py:103; confirm <= 0 hands over at step 1) */
   int32_t* hand_step;     /* [n] */
   uint8_t* hand_success;  /* [n] */
   double* hand_state;     /* [n][34] */
@@ -519,6 +521,12 @@ int kp1_set_state(kp1_env* env, const double* q, const double* dq, const double*
                   const double* goal_q, const double* goal_pose6, int32_t capture_entry_metrics);
 int kp1_rng_get(kp1_env* env, kp1_rng_state* states_host /* [N] */);
 int kp1_rng_set(kp1_env* env, const kp1_rng_state* states_host /* [N] */);
+/* Whole-state snapshot on the device (every real / integer field and the PCG64 streams of all envs), ordered on the env's stream.
+   No reference counterpart: the reference never needs one (its envs are Python objects).  Here a hipGraph capture must be preceded by
+   one eager execution of every kernel it records; kp1_state_snapshot before that warm-up and kp1_state_restore after it leave the
+   episodes and the random streams exactly where they were, so a captured rollout continues bit-identically to an eager one. */
+int kp1_state_snapshot(kp1_env* env);
+int kp1_state_restore(kp1_env* env);
 
 /* stand-alone batched kinematics (fk_interface.py:21-22, pose_utils.py:21-26): q real[n][7] -> pose6 real[n][6] */
 int kp1_fk_pose6(int32_t device, int32_t real_type, const void* q_dev, void* pose6_dev, int64_t n, void* stream);

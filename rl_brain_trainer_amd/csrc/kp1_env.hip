@@ -883,6 +883,7 @@ struct kp1_env {
   DevSampler* dev_smp = nullptr;
   kp1_handoff_state* dev_handoff = nullptr;
   int32_t n_handoff = 0;
+  void* snapshot = nullptr;    // kp1_state_snapshot: real | ints | rng64 | rng32, allocated on first use
   kp1_dock_curriculum_state* dock_tracker = nullptr;   // device tracker attached by kp1_dock_curriculum_create (its stage survives upload_cfg)
   double* opt_scratch = nullptr;  // 4*[N][7] + [N][6] doubles for explicit reset options / set_state
   const int32_t* stage_ptr = nullptr;  // kp1_bind_stage_ptr
@@ -1012,7 +1013,7 @@ __global__ void __launch_bounds__(256) eval_accumulate_kernel(const R* __restric
       F[0 * (size_t)n + i] = a; F[1 * (size_t)n + i] = 0; F[2 * (size_t)n + i] = 0; F[3 * (size_t)n + i] = 0;
       for (int f = 0; f < EVAL_STATE_W; ++f) b.state[(size_t)i * EVAL_STATE_W + f] = (double)real[(size_t)f * n + i];
       if (b.hand_metrics) {
-        for (int k = 0; k < 6; ++k) b.hand_metrics[k * (size_t)n + i] = 0.0;
+        for (int k = 0; k < 8; ++k) b.hand_metrics[k * (size_t)n + i] = 0.0;
         b.hand_step[i] = 0;
         b.hand_success[i] = 0;
         for (int f = 0; f < EVAL_STATE_W; ++f) b.hand_state[(size_t)i * EVAL_STATE_W + f] = 0.0;
@@ -1045,11 +1046,14 @@ __global__ void __launch_bounds__(256) eval_accumulate_kernel(const R* __restric
         const int streak = rdy ? C[3 * (size_t)n + i] + 1 : 0;
         C[3 * (size_t)n + i] = streak;
         if (streak > C[1 * (size_t)n + i]) C[1 * (size_t)n + i] = streak;
-        if (confirm > 0 && b.hand_metrics && !F[3 * (size_t)n + i] && streak >= confirm) {   // first-confirmed handoff snapshot
+        // first-confirmed handoff snapshot.  `ready_streak >= handoff_confirm_steps` as the reference writes it (eval_pipeline_ablation.py:103):
+        // with confirm <= 0 it holds at step 1 whatever the streak.  Whether a snapshot is wanted at all is "hand_metrics given".
+        if (b.hand_metrics && !F[3 * (size_t)n + i] && streak >= confirm) {
           F[3 * (size_t)n + i] = 1;
           double* H = b.hand_metrics;
           H[0 * (size_t)n + i] = pos; H[1 * (size_t)n + i] = ori; H[2 * (size_t)n + i] = an; H[3 * (size_t)n + i] = dqn;
           H[4 * (size_t)n + i] = mp; H[5 * (size_t)n + i] = mo;
+          H[6 * (size_t)n + i] = M[6 * (size_t)n + i]; H[7 * (size_t)n + i] = M[7 * (size_t)n + i];   // sums up to and including this step (:111-112)
           b.hand_step[i] = step;
           b.hand_success[i] = succ;
           for (int f = 0; f < EVAL_STATE_W; ++f) b.hand_state[(size_t)i * EVAL_STATE_W + f] = st[f];
@@ -1154,7 +1158,7 @@ int kp1_destroy(kp1_env* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   else (void)hipDeviceSynchronize();
   for (void* p : {(void*)e->real, (void*)e->ints, (void*)e->rng64, (void*)e->rng32, e->dev_cfg, (void*)e->dev_smp, (void*)e->dev_handoff,
-                  (void*)e->opt_scratch, e->comps})
+                  (void*)e->opt_scratch, e->comps, e->snapshot})
     (void)hipFree(p);
   delete e;
   return KP1_OK;
@@ -1477,6 +1481,26 @@ int kp1_rng_set(kp1_env* e, const kp1_rng_state* in) {
   HIP_TRY(hipStreamSynchronize(e->stream));
   return KP1_OK;
 }
+
+static int state_copy(kp1_env* e, bool save) {
+  if (!e) return fail(KP1_ERR_INVALID, "env is NULL");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t n = (size_t)e->n;
+  const size_t sizes[4] = {e->real_size() * F_NUM_REAL * n, sizeof(int32_t) * I_NUM_INT * n, sizeof(uint64_t) * 4 * n, sizeof(uint32_t) * 2 * n};
+  void* live[4] = {e->real, e->ints, e->rng64, e->rng32};
+  if (!e->snapshot) {
+    if (!save) return fail(KP1_ERR_INVALID, "kp1_state_restore without a kp1_state_snapshot");
+    HIP_TRY(hipMalloc(&e->snapshot, sizes[0] + sizes[1] + sizes[2] + sizes[3]));
+  }
+  char* shadow = (char*)e->snapshot;
+  for (int k = 0; k < 4; ++k) {
+    HIP_TRY(hipMemcpyAsync(save ? (void*)shadow : live[k], save ? live[k] : (const void*)shadow, sizes[k], hipMemcpyDeviceToDevice, e->stream));
+    shadow += sizes[k];
+  }
+  return KP1_OK;
+}
+int kp1_state_snapshot(kp1_env* e) { return state_copy(e, true); }
+int kp1_state_restore(kp1_env* e) { return state_copy(e, false); }
 
 #ifdef KP1_ENV_TRACE
 int kp1_debug_env_trace(unsigned long long* out, int clear) {

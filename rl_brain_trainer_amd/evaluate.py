@@ -194,12 +194,14 @@ _STATE_SLICES = (("q", 0, 7), ("dq", 7, 14), ("prev_action", 14, 21), ("goal_q",
 _ALIVE_CHECK_EVERY = 8      # env steps between two reads of the device's alive-episode counter
 
 
-def run_episodes(env: ArmKinematicVecEnv, policy: PolicyFn, reset_options: dict[str, Any], *, ready_cfg=None, handoff_confirm_steps: int = 0,
+def run_episodes(env: ArmKinematicVecEnv, policy: PolicyFn, reset_options: dict[str, Any], *, ready_cfg=None, handoff_confirm_steps: int | None = None,
                  active: torch.Tensor | None = None, max_steps: int | None = None) -> tuple[dict[str, torch.Tensor], dict[str, torch.Tensor] | None]:
     """All episodes in lock step until each has terminated or truncated (_run_policy / _run_approach_with_handoff).
 
-    Returns (final_result, handoff_result): tensors over episodes.  handoff_result (if handoff_confirm_steps > 0) is the
-    snapshot at the first step where the ready streak reached handoff_confirm_steps, with ``valid`` marking who has one.
+    Returns (final_result, handoff_result): tensors over episodes.  ``handoff_confirm_steps=None`` is the reference's _run_policy (no
+    handoff bookkeeping, handoff_result None); an integer is _run_approach_with_handoff: handoff_result is the snapshot at the first
+    step where ``ready_streak >= handoff_confirm_steps`` (eval_pipeline_ablation.py:103 -- so 0 or less hands over at step 1), with
+    ``valid`` marking who has one, and carries the action / dq means up to that step like the reference's dict.
 
     Per env step: the policy, the norm of its action, kp1_step, and ONE kp1_eval_accumulate launch that does the whole per-episode
     bookkeeping on the device (finals / minima / sums, success, state snapshot, ready streak, first-confirmed handoff snapshot, alive
@@ -218,8 +220,9 @@ def run_episodes(env: ArmKinematicVecEnv, policy: PolicyFn, reset_options: dict[
     flags = torch.empty((4, E), dtype=u8, device=dev)
     state = torch.empty((E, 34), dtype=f64, device=dev)
     n_alive = torch.zeros(1, dtype=i32, device=dev)
-    want_hand = handoff_confirm_steps > 0
-    hand_metrics = torch.empty((6, E), dtype=f64, device=dev) if want_hand else None
+    want_hand = handoff_confirm_steps is not None and ready_cfg is not None
+    confirm = int(handoff_confirm_steps or 0)
+    hand_metrics = torch.empty((8, E), dtype=f64, device=dev) if want_hand else None
     hand_step = torch.empty(E, dtype=i32, device=dev) if want_hand else None
     hand_success = torch.empty(E, dtype=u8, device=dev) if want_hand else None
     hand_state = torch.empty((E, 34), dtype=f64, device=dev) if want_hand else None
@@ -231,7 +234,7 @@ def run_episodes(env: ArmKinematicVecEnv, policy: PolicyFn, reset_options: dict[
         thr = (C.c_double * 4)(ready_cfg.dock_coarse_ready_pos_threshold_m, ready_cfg.dock_coarse_ready_ori_threshold_rad,
                                ready_cfg.dock_coarse_ready_action_threshold, ready_cfg.dock_coarse_ready_dq_threshold)
     act_mask = None if active is None else active.to(dev).to(u8).contiguous()
-    native.check(L.kp1_eval_accumulate(env._handle, C.byref(bufs), None, None, ptr(act_mask), 0, thr, int(handoff_confirm_steps), None))
+    native.check(L.kp1_eval_accumulate(env._handle, C.byref(bufs), None, None, ptr(act_mask), 0, thr, confirm, None))
     limit = int(max_steps or (env.config.c.termination.max_episode_steps + 1))
     for step in range(1, limit + 1):
         if (step - 1) % _ALIVE_CHECK_EVERY == 0 and int(n_alive.item()) == 0:
@@ -240,7 +243,7 @@ def run_episodes(env: ArmKinematicVecEnv, policy: PolicyFn, reset_options: dict[
         a_norm = torch.linalg.vector_norm(action.double(), dim=1).contiguous()
         obs, _, done = env.step(action, auto_reset=False)
         obs = obs.clone()
-        native.check(L.kp1_eval_accumulate(env._handle, C.byref(bufs), ptr(a_norm), ptr(done), None, step, thr, int(handoff_confirm_steps), None))
+        native.check(L.kp1_eval_accumulate(env._handle, C.byref(bufs), ptr(a_norm), ptr(done), None, step, thr, confirm, None))
     res = {
         "success": flags[1].bool(), "final_position_error": metrics[0], "final_orientation_error": metrics[1], "min_position_error": metrics[2],
         "min_orientation_error": metrics[3], "final_action_magnitude": metrics[4], "final_dq_norm": metrics[5], "sum_action": metrics[6],
@@ -256,20 +259,22 @@ def run_episodes(env: ArmKinematicVecEnv, policy: PolicyFn, reset_options: dict[
         hand = {"valid": flags[3].bool(), "final_position_error": hand_metrics[0], "final_orientation_error": hand_metrics[1],
                 "final_action_magnitude": hand_metrics[2], "final_dq_norm": hand_metrics[3], "min_position_error": hand_metrics[4],
                 "min_orientation_error": hand_metrics[5], "step_count": hand_step, "success": hand_success.bool()}
+        hsteps = hand_step.clamp_min(1).double()
+        hand["mean_action_magnitude"] = hand_metrics[6] / hsteps
+        hand["mean_dq_norm"] = hand_metrics[7] / hsteps
         for k, lo, hi in _STATE_SLICES:
             hand["state_" + k] = hand_state[:, lo:hi].contiguous()
     return res, hand
 
 
-def _run_episodes_reference(env: ArmKinematicVecEnv, policy: PolicyFn, reset_options: dict[str, Any], *, ready_cfg=None, handoff_confirm_steps: int = 0,
+def _run_episodes_reference(env: ArmKinematicVecEnv, policy: PolicyFn, reset_options: dict[str, Any], *, ready_cfg=None, handoff_confirm_steps: int | None = None,
                  active: torch.Tensor | None = None, max_steps: int | None = None) -> tuple[dict[str, torch.Tensor], dict[str, torch.Tensor] | None]:
     """The per-step bookkeeping as tensor expressions (about 45 launches and two host synchronisations per env step): the form
     run_episodes had before kp1_eval_accumulate, kept as the test reference the device kernel is compared with bit for bit.
 
     All episodes in lock step until each has terminated or truncated (_run_policy / _run_approach_with_handoff).
 
-    Returns (final_result, handoff_result): tensors over episodes.  handoff_result (if handoff_confirm_steps > 0) is the
-    snapshot at the first step where the ready streak reached handoff_confirm_steps, with ``valid`` marking who has one."""
+    Returns (final_result, handoff_result) as run_episodes does."""
     E = env.n_envs
     dev = env.device
     obs = env.reset(options=reset_options).clone()
@@ -289,8 +294,9 @@ def _run_episodes_reference(env: ArmKinematicVecEnv, policy: PolicyFn, reset_opt
     streak = torch.zeros(E, dtype=torch.int32, device=dev)
     state = _snapshot(env)
     hand = None
-    if handoff_confirm_steps > 0:
+    if handoff_confirm_steps is not None and ready_cfg is not None:
         hand = {"valid": torch.zeros(E, dtype=torch.bool, device=dev)}
+        hsum = {"a": torch.zeros(E, dtype=f64, device=dev), "d": torch.zeros(E, dtype=f64, device=dev)}
     limit = int(max_steps or (env.config.c.termination.max_episode_steps + 1))
     for step in range(1, limit + 1):
         if not bool(alive.any()):
@@ -323,6 +329,8 @@ def _run_episodes_reference(env: ArmKinematicVecEnv, policy: PolicyFn, reset_opt
             res["max_ready_streak"] = torch.maximum(res["max_ready_streak"], streak)
             if hand is not None:
                 take = upd & (~hand["valid"]) & (streak >= handoff_confirm_steps)
+                hsum["a"] = torch.where(take, res["sum_action"], hsum["a"])
+                hsum["d"] = torch.where(take, res["sum_dq"], hsum["d"])
                 if bool(take.any()):
                     cur = {"final_position_error": pos, "final_orientation_error": ori, "final_action_magnitude": a_norm, "final_dq_norm": dqn,
                            "min_position_error": res["min_position_error"], "min_orientation_error": res["min_orientation_error"],
@@ -339,6 +347,10 @@ def _run_episodes_reference(env: ArmKinematicVecEnv, policy: PolicyFn, reset_opt
     res["mean_dq_norm"] = res["sum_dq"] / steps
     for k, v in state.items():
         res["state_" + k] = v
+    if hand is not None and "step_count" in hand:
+        hsteps = hand["step_count"].clamp_min(1).double()
+        hand["mean_action_magnitude"] = hsum["a"] / hsteps
+        hand["mean_dq_norm"] = hsum["d"] / hsteps
     return res, hand
 
 

@@ -86,6 +86,8 @@ def load() -> C.CDLL:
     L.kp1_set_state.argtypes = [vp] + [vp] * 5 + [i32]
     L.kp1_rng_get.argtypes = [vp, vp]
     L.kp1_rng_set.argtypes = [vp, vp]
+    L.kp1_state_snapshot.argtypes = [vp]
+    L.kp1_state_restore.argtypes = [vp]
     L.kp1_fk_pose6.argtypes = [i32, i32, vp, vp, i64, vp]
     L.kp1_pose_error.argtypes = [i32, i32, vp, vp, vp, vp, vp, i64, vp]
     L.kp1_joint_utils.argtypes = [i32, i32, C.POINTER(kcfg.Kp1Config), vp, vp, vp, vp, vp, vp, i64, vp]

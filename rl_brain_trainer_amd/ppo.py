@@ -663,24 +663,31 @@ class PPO:
     def _capture_rollout(self) -> None:
         """Record the T-step rollout (policy forward, env step, curriculum tracker; data parallel: the done-byte all-gather of every chunk)
         once; every later rollout is one replay.  The kernels must have run once before a capture (code objects loaded, attributes set).  At
-        the very start that is a warm-up step followed by a fresh reset (the episodes have not begun); a RE-capture in the middle of
-        training (an env setter or a hyper-parameter changed, a step callback was removed) finds them warm from the rollouts already done and
-        leaves the running episodes untouched."""
+        the very start that is a warm-up step between a device snapshot of the env state and its restore; a RE-capture in the middle of
+        training (an env setter or a hyper-parameter changed, a step callback was removed) finds them warm from the rollouts already done.
+        Either way the running episodes and random streams are untouched."""
         T = self.cfg.n_steps
         if not self._kernels_warm:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
+            can_snapshot = hasattr(self.env, "snapshot")
             with torch.cuda.stream(side):
                 self.env.use_current_stream()
+                if can_snapshot:
+                    self.env.snapshot()      # the warm-up step below must not move the episodes or the random streams
                 self._mlp.forward(self.obs_buf[0], noise=self.noise_all[0], value=self.val_buf[0], action=self.act_buf[0],
                                   clipped=self.clip_act, log_prob=self.logp_buf[0])
                 self.env.step_into(self.clip_act, self.obs_buf[1], self.rew_buf[0], self.done_buf[0], self.term_obs_buf[0], True)
                 if self.curriculum is not None:
                     self.curriculum.observe(self.done_buf[0].zero_(), 0)   # also loads the module the chunk form of the tracker lives in
                 self._post_rollout()                                        # the graph's tail, once eagerly (its buffers are rewritten by the real rollout)
-                # the warm-up moved every env one step: start the episodes again (one extra reset() draw per env stream)
                 self.env.use_current_stream()
-                self.obs_buf[0].copy_(self.env.reset())
+                if can_snapshot:
+                    self.env.restore()       # a captured rollout therefore continues exactly like an eager one (tests/test_distributed_gpu.py)
+                else:
+                    # wrappers without a device snapshot (the route env keeps state of its own): start the episodes again instead, at the
+                    # price of one extra reset() draw per env stream
+                    self.obs_buf[0].copy_(self.env.reset())
             torch.cuda.current_stream(self.device).wait_stream(side)
             self._kernels_warm = True
         torch.cuda.synchronize(self.device)
@@ -785,10 +792,16 @@ class PPO:
                 continue
             perm = self._draw_perm(total)
             mb_stats = self._epoch_adv_stats(adv, perm, total, local_bs) if self._mlp is not None else None
+            if self._mlp is not None:
+                # the eager loop steps Adam from the device-resident step count too, exactly as the captured epoch does (bias corrections
+                # computed by the same device arithmetic): eager and replayed training stay bit-identical.  The count is set from the host
+                # mirror first, so loss_grad calls made outside train() cannot have moved it.
+                self._mlp.set_step_count(self.adam_t)
             for i, start in enumerate(range(0, total, local_bs)):
                 idx = perm[start:start + local_bs]
                 if self._mlp is not None:
-                    self._hip_minibatch_step(obs, idx, act, old_logp, adv, ret, adv_stats=None if mb_stats is None else mb_stats[i])
+                    self._hip_minibatch_step(obs, idx, act, old_logp, adv, ret, device_step=True, adv_stats=None if mb_stats is None else mb_stats[i])
+                    self.adam_t += 1
                 else:
                     stats += self._minibatch_step(obs[idx], act[idx], old_logp[idx], adv[idx], ret[idx])
                 n_updates += 1

@@ -204,6 +204,14 @@ class ArmKinematicVecEnv:
         """Order this handle's launches on torch's current stream (call inside torch.cuda.graph capture / stream contexts)."""
         native.check(self.L.kp1_set_stream(self._handle, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
+    def snapshot(self) -> None:
+        """Device-side copy of the whole env state (all fields, counters and PCG64 streams), ordered on the handle's stream."""
+        native.check(self.L.kp1_state_snapshot(self._handle))
+
+    def restore(self) -> None:
+        """Put the state of the last snapshot() back (episodes and random streams continue exactly from there)."""
+        native.check(self.L.kp1_state_restore(self._handle))
+
     def step_into(self, actions: torch.Tensor, obs: torch.Tensor, reward: torch.Tensor, done: torch.Tensor,
                   terminal_obs: torch.Tensor | None, auto_reset: bool = True) -> None:
         """Zero-copy variant used by the rollout loop: outputs go straight into caller-owned (rollout) buffers."""

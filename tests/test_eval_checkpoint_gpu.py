@@ -225,8 +225,9 @@ def test_resume_restores_adam_state(tmp_path):
         e.close()
 
 
-@pytest.mark.parametrize("cfg_name,real,confirm,masked", [("approach_dock_coarse_ready_v1", "f32", 2, False), ("fuzz1_approach", "f32", 0, True),
-                                                          ("fuzz1_approach", "f64", 3, True), ("fuzz2_approach", "f32", 2, False)])
+@pytest.mark.parametrize("cfg_name,real,confirm,masked", [("approach_dock_coarse_ready_v1", "f32", 2, False), ("fuzz1_approach", "f32", None, True),
+                                                          ("fuzz1_approach", "f64", 3, True), ("fuzz2_approach", "f32", 2, False),
+                                                          ("fuzz2_approach", "f32", 0, True)])
 def test_device_eval_bookkeeping_equals_tensor_expressions(cfg_name, real, confirm, masked):
     """kp1_eval_accumulate (one launch per env step) against the tensor-expression form of the evaluator's bookkeeping
     (_run_episodes_reference): 600 episodes from sampled resets under a noisy servo of mixed gains -- episodes succeed and terminate early
@@ -263,11 +264,16 @@ def test_device_eval_bookkeeping_equals_tensor_expressions(cfg_name, real, confi
     if cfg.c.termination.terminate_on_success:
         steps = ref["step_count"][ref["step_count"] > 0]
         assert int(steps.max()) > int(steps.min()) and bool(ref["success"].any())     # ... and episodes of different lengths
-    if confirm:
-        assert bool(ref_hand["valid"].any()) and not bool(ref_hand["valid"].all())
+    if confirm is None:                                      # _run_policy: no handoff bookkeeping at all
+        assert hand is None and ref_hand is None
+    else:
+        if confirm > 0:
+            assert bool(ref_hand["valid"].any()) and not bool(ref_hand["valid"].all())
+        else:                                                # ready_streak >= 0 holds at step 1 (eval_pipeline_ablation.py:103): every episode hands over there
+            live = active if active is not None else torch.ones(E, dtype=torch.bool, device="cuda")
+            assert torch.equal(ref_hand["valid"], live) and bool((ref_hand["step_count"][live] == 1).all())
+        assert set(hand) == set(ref_hand) and {"mean_action_magnitude", "mean_dq_norm"} <= set(hand)
         for k in ref_hand:                                   # the reference creates a handoff entry when the first episode hands over
             assert hand[k].dtype == ref_hand[k].dtype and torch.equal(hand[k], ref_hand[k]), k
-    else:
-        assert hand is None and ref_hand is None
     if masked:
         assert torch.equal(res["step_count"][~active], torch.zeros_like(res["step_count"][~active]))
