@@ -238,15 +238,23 @@ struct EnvState {
   uint64_t* rng64; // [4][N]: state_hi, state_lo, inc_hi, inc_lo
   uint32_t* rng32; // [2][N]: has_uint32, uinteger
   int64_t n;
-  // Address of element i of field plane f = (wave-uniform plane base: scalar arithmetic) + (32-bit byte offset of the lane): the loads and
-  // stores take the SGPR-base addressing form, instead of a 64-bit multiply-add chain per field per lane (it was a tenth of the step's
-  // vector instructions).  kp1_create bounds n so that the byte offset fits 32 bits.
+  // Address of element i of field plane f = ONE wave-uniform base (the array itself, an SGPR pair) + a 32-bit byte offset per lane,
+  // (f * n + i) * sizeof(T): the loads and stores take the SGPR-base + 32-bit-offset form and the offset costs one 32-bit multiply-add,
+  // instead of a 64-bit multiply-add chain per field per lane (it was a tenth of the step's vector instructions).  A separate 64-bit
+  // scalar base per PLANE would be cheaper still per access, but 57 of them do not fit the 102 SGPRs: the compiler spills them to
+  // vector-register lanes, and in the largest kernel (kp1_route_step_kernel<double>: 512 registers + scratch) those lanes were themselves
+  // spilled to scratch inside the divergent auto-reset region and came back wrong -- a wild scalar base, HSA_STATUS_ERROR_MEMORY_APERTURE_
+  // VIOLATION at the first in-launch route reset (round 3, gpurun_out/r03_dbg1.log).  kp1_create bounds n so that the offset fits 32 bits.
   template <typename T>
-  static __device__ __forceinline__ T& at(T* plane, int64_t i) {
-    return plane[(uint32_t)i];
+  static __device__ __forceinline__ T& at(T* base, int f, int64_t n, int64_t i) {
+#ifdef KP1_OLD_PLANE_ADDR
+    return base[(int64_t)f * n + i];
+#else
+    return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + ((uint32_t)f * (uint32_t)n + (uint32_t)i) * (uint32_t)sizeof(T));
+#endif
   }
-  __device__ __forceinline__ R& r(int f, int64_t i) const { return at<R>(real + (int64_t)f * n, i); }
-  __device__ __forceinline__ int32_t& iv(int f, int64_t i) const { return at<int32_t>(ints + (int64_t)f * n, i); }
+  __device__ __forceinline__ R& r(int f, int64_t i) const { return at<R>(real, f, n, i); }
+  __device__ __forceinline__ int32_t& iv(int f, int64_t i) const { return at<int32_t>(ints, f, n, i); }
   // joint position as the kinematic chain carries it (fp64).  fp32 handle: a two-float value, 48 significant bits.
   __device__ __forceinline__ double q_load(int k, int64_t i) const {
     if constexpr (sizeof(R) == 4) return (double)r(F_Q + k, i) + (double)r(F_QLO + k, i);

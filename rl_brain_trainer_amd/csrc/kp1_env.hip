@@ -67,21 +67,22 @@ struct ResetOptsDev {
   int flags;
 };
 
+// PCG64 planes [4][N] u64 + [2][N] u32: one scalar base per array + a 32-bit lane offset per plane, as EnvState::at
 __device__ __forceinline__ void rng_load(const uint64_t* __restrict__ r64, const uint32_t* __restrict__ r32, int64_t n, int64_t i, Pcg& r) {
-  const uint32_t o8 = (uint32_t)i * 8u, o4 = (uint32_t)i * 4u;   // plane base (uniform) + 32-bit lane offset, as EnvState::at
-  auto w64 = [&](int plane) { return *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(r64 + plane * n) + o8); };
-  auto w32 = [&](int plane) { return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(r32 + plane * n) + o4); };
+  auto w64 = [&](int plane) { return *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(r64) + ((uint32_t)plane * (uint32_t)n + (uint32_t)i) * 8u); };
+  auto w32 = [&](int plane) { return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(r32) + ((uint32_t)plane * (uint32_t)n + (uint32_t)i) * 4u); };
   r.state = ((unsigned __int128)w64(0) << 64) | w64(1);
   r.inc = ((unsigned __int128)w64(2) << 64) | w64(3);
   r.has_uint32 = w32(0);
   r.uinteger = w32(1);
 }
 __device__ __forceinline__ void rng_store(uint64_t* __restrict__ r64, uint32_t* __restrict__ r32, int64_t n, int64_t i, const Pcg& r) {
-  const uint32_t o8 = (uint32_t)i * 8u, o4 = (uint32_t)i * 4u;
-  *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(r64 + 0 * n) + o8) = (uint64_t)(r.state >> 64);
-  *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(r64 + 1 * n) + o8) = (uint64_t)r.state;
-  *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(r32 + 0 * n) + o4) = r.has_uint32;
-  *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(r32 + 1 * n) + o4) = r.uinteger;
+  auto p64 = [&](int plane) { return reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(r64) + ((uint32_t)plane * (uint32_t)n + (uint32_t)i) * 8u); };
+  auto p32 = [&](int plane) { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(r32) + ((uint32_t)plane * (uint32_t)n + (uint32_t)i) * 4u); };
+  *p64(0) = (uint64_t)(r.state >> 64);
+  *p64(1) = (uint64_t)r.state;
+  *p32(0) = r.has_uint32;
+  *p32(1) = r.uinteger;
 }
 
 // one observation row = 14 float4 stores (+2 zero float4 when the row pitch is the MFMA-friendly 64)
@@ -297,8 +298,11 @@ struct StepArgs {
   const int32_t* stage_ptr;  // device-resident curriculum stage (kp1_bind_stage_ptr) or nullptr
 };
 
+#ifndef KP1_STEP_MIN_WAVES
+#define KP1_STEP_MIN_WAVES 1   // minimum waves per SIMD the register allocation must leave room for (launch_bounds' second argument)
+#endif
 template <typename R, int MODE, bool COMPS>
-__global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
+__global__ void __launch_bounds__(256, KP1_STEP_MIN_WAVES) kp1_step_kernel(const StepArgs<R> a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n = a.st.n;
   if (i >= n) return;
@@ -455,7 +459,11 @@ __global__ void __launch_bounds__(256) kp1_step_kernel(const StepArgs<R> a) {
   const bool done = terminated || truncated;
   a.done[i] = (uint8_t)((terminated ? KP1_DONE_TERMINATED : 0) | (truncated ? KP1_DONE_TRUNCATED : 0) |
                         (success ? KP1_DONE_SUCCESS : 0) | (invalid ? KP1_DONE_INVALID : 0));
+#ifdef KP1_STEP_NO_RESET_PROBE   // developer probe: register footprint of the step path alone
+  if (false) {
+#else
   if (done && a.auto_reset) {
+#endif
     // VecEnv auto-reset: keep the finished episode's last observation + info norms, then reset in place.
     if (a.terminal_obs) store_obs_row(a.terminal_obs, i, o, a.obs_stride);
     ResetOptsDev none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
@@ -1099,7 +1107,7 @@ int kp1_create(const kp1_config* cfg, int32_t n_envs, int32_t device, int32_t re
                void* stream, kp1_env** out) {
   if (!cfg || !out) return fail(KP1_ERR_INVALID, "cfg/out is NULL");
   if (n_envs <= 0) return fail(KP1_ERR_INVALID, "n_envs must be positive");
-  if (n_envs > (1 << 28)) return fail(KP1_ERR_INVALID, "n_envs above 2^28: a lane's byte offset inside a state plane must fit 32 bits");
+  if (n_envs > (1 << 22)) return fail(KP1_ERR_INVALID, "n_envs above 2^22: a lane's byte offset inside the state arrays ((field * n + env) * 8) must fit 32 bits");
   if (real_type != KP1_REAL_F32 && real_type != KP1_REAL_F64) return fail(KP1_ERR_INVALID, "real_type must be KP1_REAL_F32 or KP1_REAL_F64");
   if (cfg->env.mode != KP1_MODE_APPROACH && cfg->env.mode != KP1_MODE_DOCK) return fail(KP1_ERR_UNSUPPORTED, "mode must be approach or dock");
   if (cfg->n_stages < 0 || cfg->n_stages > KP1_MAX_STAGES) return fail(KP1_ERR_INVALID, "n_stages out of range");
