@@ -301,11 +301,14 @@ struct StepArgs {
 #ifndef KP1_STEP_MIN_WAVES
 #define KP1_STEP_MIN_WAVES 1   // minimum waves per SIMD the register allocation must leave room for (launch_bounds' second argument)
 #endif
+// One env step of lane i, auto-reset of a finished env included (VecEnv semantics).
+// [round 3, measured and removed] A split form for large batches -- this body without the reset branch under launch_bounds(256, 2), i.e. two
+// waves per SIMD instead of one, plus a second kernel that resets the finished envs -- is bit-identical and NOT faster: 116.9 us for the step
+// kernel alone at 524288 envs against 116-120 us fused (profiles/r03_ab_env_split_step.log).  Occupancy is not what bounds the large-batch
+// rate; the 110 dword-per-lane accesses of a step are (each wave instruction touches 256 bytes of a different 2 MB plane): DESIGN.md 4.5.
 template <typename R, int MODE, bool COMPS>
-__global__ void __launch_bounds__(256, KP1_STEP_MIN_WAVES) kp1_step_kernel(const StepArgs<R> a) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void step_env_lane(const StepArgs<R>& a, const int64_t i) {
   const int64_t n = a.st.n;
-  if (i >= n) return;
   KP1_ETR(0)
 #ifndef KP1_CFG_VEC
 #define KP1_CFG_VEC 0     // 0: config through scalar loads; 1: the FK constants through lane_view; 2: the whole block through lane_view
@@ -459,11 +462,7 @@ __global__ void __launch_bounds__(256, KP1_STEP_MIN_WAVES) kp1_step_kernel(const
   const bool done = terminated || truncated;
   a.done[i] = (uint8_t)((terminated ? KP1_DONE_TERMINATED : 0) | (truncated ? KP1_DONE_TRUNCATED : 0) |
                         (success ? KP1_DONE_SUCCESS : 0) | (invalid ? KP1_DONE_INVALID : 0));
-#ifdef KP1_STEP_NO_RESET_PROBE   // developer probe: register footprint of the step path alone
-  if (false) {
-#else
   if (done && a.auto_reset) {
-#endif
     // VecEnv auto-reset: keep the finished episode's last observation + info norms, then reset in place.
     if (a.terminal_obs) store_obs_row(a.terminal_obs, i, o, a.obs_stride);
     ResetOptsDev none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
@@ -505,6 +504,13 @@ __global__ void __launch_bounds__(256, KP1_STEP_MIN_WAVES) kp1_step_kernel(const
   __builtin_amdgcn_s_waitcnt(0);   // every store of this wave acknowledged
   KP1_ETR(9)
 #endif
+}
+
+template <typename R, int MODE, bool COMPS>
+__global__ void __launch_bounds__(256, KP1_STEP_MIN_WAVES) kp1_step_kernel(const StepArgs<R> a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.st.n) return;
+  step_env_lane<R, MODE, COMPS>(a, i);
 }
 
 template <typename R, int MODE>
@@ -904,6 +910,7 @@ struct kp1_env {
 namespace {
 
 int block_for(int64_t n) { return n <= 65536 ? 64 : 256; }
+
 
 template <typename R>
 EnvState<R> state_of(const kp1_env* e) {
