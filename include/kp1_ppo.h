@@ -167,6 +167,14 @@ int kp1_mlp_pack_weights(kp1_mlp* m, const float* params, void* stream);
 int kp1_mlp_forward(kp1_mlp* m, const float* obs, int32_t obs_stride, int32_t n, const float* noise, float* mean, float* value,
                     float* action, float* clipped_action, float* log_prob, void* stream);
 
+/* One rollout step in ONE launch: policy.forward on the current observations of ALL envs of `env` (row m = env m; obs f32 [N][obs_stride]),
+ * Gaussian sampling, then VecEnv.step(clip(action)) of every env with the auto-reset -- SB3's collect_rollouts body
+ * (on_policy_algorithm.py: policy(obs) -> clip -> env.step) without the action round trip through HBM and without a launch for the env.
+ * Same results as kp1_mlp_forward followed by kp1_step (tests/test_ppo_kernels_gpu.py).  fp32 handles, hidden 256, 56-float observations;
+ * reward components must be off.  value / log_prob may be NULL (value NULL skips the value net); terminal_obs may be NULL. */
+int kp1_mlp_forward_env_step(kp1_mlp* m, kp1_env* env, const float* obs, int32_t obs_stride, const float* noise, float* value, float* action,
+                             float* log_prob, float* next_obs, float* reward, uint8_t* done, float* terminal_obs, void* stream);
+
 /* one PPO minibatch: forward + loss + full backward.  Rows are gathered through idx (int64 [n] into the [total] axis, or
  * NULL = rows 0..n).  grad_out f32 [num_params] receives d loss / d params in SB3 order (overwritten), with
  *   loss = sum_i[-min(r_i A_i, clip(r_i, 1-c, 1+c) A_i)] * inv_count + vf_coef * sum_i (R_i - V_i)^2 * inv_count - ent_coef * H,

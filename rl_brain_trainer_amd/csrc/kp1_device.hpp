@@ -402,9 +402,10 @@ __device__ __forceinline__ void pose_error_norms(const R* curr, const R* goal, R
 }
 template <typename R>
 __device__ __forceinline__ R norm7(const R* v) {
+#pragma clang fp contract(off)
   R s = 0;
 #pragma unroll
-  for (int i = 0; i < NJ; ++i) s += v[i] * v[i];
+  for (int i = 0; i < NJ; ++i) s = kp_fma(v[i], v[i], s);   // explicit: the same bits in every kernel this is inlined into
   return kp_sqrt(s);
 }
 

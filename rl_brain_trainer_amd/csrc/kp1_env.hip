@@ -28,489 +28,13 @@ using namespace kp1;
 // ============================================================================================
 namespace {
 
-// Developer timeline of the step kernel (tools/env_timeline.py builds a private copy with -DKP1_ENV_TRACE): lane 0 of every wave stamps the
-// shader clock (s_memtime) at the phase boundaries.  Compiled out of the product.
-#ifdef KP1_ENV_TRACE
-constexpr int KP1_ENV_TRACE_SLOTS = 16, KP1_ENV_TRACE_WAVES = 1024;
-__device__ unsigned long long kp1_env_trace_buf[KP1_ENV_TRACE_SLOTS * KP1_ENV_TRACE_WAVES];
-// KP1_ETR_PIN(slot, v...): the values a phase produces are made "used" right before the stamp, so that neither the optimiser nor the
-// scheduler can sink the phase's work below it
-__device__ __forceinline__ void etr_pin(float v) { asm volatile("" ::"v"(v)); }
-__device__ __forceinline__ void etr_pin(double v) { asm volatile("" ::"v"(v)); }
-__device__ __forceinline__ void etr_pin(int v) { asm volatile("" ::"v"(v)); }
-#define KP1_ETR_PIN(slot, ...)                                                                                                    \
-  {                                                                                                                               \
-    for (auto pv_ : {__VA_ARGS__}) etr_pin(pv_);                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                                            \
-    KP1_ETR(slot)                                                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                                                            \
-  }
-#define KP1_ETR(slot)                                                                                                             \
-  {                                                                                                                               \
-    const unsigned long long t_ = __builtin_readcyclecounter();                                                                   \
-    const int w_ = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);                                                           \
-    if ((threadIdx.x & 63) == 0 && w_ < KP1_ENV_TRACE_WAVES) kp1_env_trace_buf[w_ * KP1_ENV_TRACE_SLOTS + (slot)] = t_;           \
-  }
-#else
-#define KP1_ETR(slot)
-#define KP1_ETR_PIN(slot, ...)
-#endif
-
-constexpr int OPT_INITIAL_Q = 1, OPT_INITIAL_DQ = 2, OPT_INITIAL_PREV_ACTION = 4, OPT_GOAL_Q = 8, OPT_GOAL_POSE6 = 16;
-
-struct ResetOptsDev {
-  const double* initial_q;            // [N][7] row-major (device scratch), or nullptr
-  const double* initial_dq;
-  const double* initial_prev_action;
-  const double* goal_q;
-  const double* goal_pose6;           // [N][6]
-  int flags;
-};
-
-// PCG64 planes [4][N] u64 + [2][N] u32: one scalar base per array + a 32-bit lane offset per plane, as EnvState::at
-__device__ __forceinline__ void rng_load(const uint64_t* __restrict__ r64, const uint32_t* __restrict__ r32, int64_t n, int64_t i, Pcg& r) {
-  auto w64 = [&](int plane) { return *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(r64) + ((uint32_t)plane * (uint32_t)n + (uint32_t)i) * 8u); };
-  auto w32 = [&](int plane) { return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(r32) + ((uint32_t)plane * (uint32_t)n + (uint32_t)i) * 4u); };
-  r.state = ((unsigned __int128)w64(0) << 64) | w64(1);
-  r.inc = ((unsigned __int128)w64(2) << 64) | w64(3);
-  r.has_uint32 = w32(0);
-  r.uinteger = w32(1);
-}
-__device__ __forceinline__ void rng_store(uint64_t* __restrict__ r64, uint32_t* __restrict__ r32, int64_t n, int64_t i, const Pcg& r) {
-  auto p64 = [&](int plane) { return reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(r64) + ((uint32_t)plane * (uint32_t)n + (uint32_t)i) * 8u); };
-  auto p32 = [&](int plane) { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(r32) + ((uint32_t)plane * (uint32_t)n + (uint32_t)i) * 4u); };
-  *p64(0) = (uint64_t)(r.state >> 64);
-  *p64(1) = (uint64_t)r.state;
-  *p32(0) = r.has_uint32;
-  *p32(1) = r.uinteger;
-}
-
-// one observation row = 14 float4 stores (+2 zero float4 when the row pitch is the MFMA-friendly 64)
-__device__ __forceinline__ void store_obs_row(float* __restrict__ obs, int64_t i, const float* o, int stride = KP1_OBS_DIM) {
-  float4* dst = reinterpret_cast<float4*>(obs + i * stride);
-#pragma unroll
-  for (int k = 0; k < KP1_OBS_DIM / 4; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
-  if (stride > KP1_OBS_DIM) {
-    dst[14] = make_float4(0.f, 0.f, 0.f, 0.f);
-    dst[15] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-}
-
-// Sampling half of reset(): fills a ResetSample in fp64.  KP1/envs/reset_samplers.py:168-210, 426-515.
-template <int MODE>
-__device__ __forceinline__ void sample_reset(const DevSampler& __restrict__ s, const kp1_handoff_state* __restrict__ handoff, Pcg& rng,
-                                          int stage_index, ResetSample& o, bool& has_dq_pa, bool& has_goal_pose) {
-  has_dq_pa = false;
-  has_goal_pose = false;
-  o.stage = 0;
-  if constexpr (MODE == KP1_MODE_DOCK) {
-    const kp1_dock_reset& c = s.dr;
-    if (c.handoff_state_probability > 0.0 && s.n_handoff > 0 && pcg_double(rng) < c.handoff_state_probability) {
-      const kp1_handoff_state& h = handoff[s.handoff_offset + pcg_integers(rng, 0, s.n_handoff)];
-      for (int k = 0; k < NJ; ++k) {
-        o.initial_q[k] = h.initial_q[k];
-        o.goal_q[k] = h.goal_q[k];
-        o.initial_dq[k] = h.initial_dq[k];
-        o.initial_prev_action[k] = h.initial_prev_action[k];
-      }
-      for (int k = 0; k < 6; ++k) o.goal_pose6[k] = h.goal_pose6[k];
-      has_dq_pa = true;
-      has_goal_pose = true;
-      return;
-    }
-    if (s.curriculum_enabled && s.n_stages > 0) {
-      int idx = kp_clipi(stage_index, 0, s.n_stages - 1);
-      sample_stage_joint_target(s, rng, s.stages[idx].goal_q, s.stages[idx].goal_noise, o.goal_q);
-      o.stage = idx;
-    } else {
-      sample_stage_joint_target(s, rng, c.goal_q, c.goal_noise, o.goal_q);
-    }
-    if (c.close_bucket_probability > 0.0 && pcg_double(rng) < c.close_bucket_probability) {
-      // _sample_close_bucket_initial_q :474-515 (fp64 FK decides acceptance)
-      double goal_pose[6];
-      fk_pose6<double>(s.fk, o.goal_q, goal_pose);
-      double best_q[NJ];
-      bool have_best = false;
-      double best_dist = INFINITY;
-      int attempts = kp_maxi(c.close_bucket_max_attempts, 1);
-      bool accepted = false;
-      for (int a = 0; a < attempts && !accepted; ++a) {
-        double d[NJ], cand[NJ], pose[6], pe[3], oe[3], pn, on;
-        pcg_uniform_sym7(rng, c.close_init_q_noise, d);
-        for (int k = 0; k < NJ; ++k) cand[k] = dclip(o.goal_q[k] + d[k], s.lower[k], s.upper[k]);
-        fk_pose6<double>(s.fk, cand, pose);
-        pose_error_norms<double>(pose, goal_pose, pe, oe, &pn, &on);
-        if (c.close_bucket_min_pos_error_m <= pn && pn <= c.close_bucket_max_pos_error_m &&
-            on >= c.close_bucket_min_ori_error_rad && on <= c.close_bucket_max_ori_error_rad) {
-          for (int k = 0; k < NJ; ++k) o.initial_q[k] = cand[k];
-          accepted = true;
-          break;
-        }
-        double bd;
-        if (pn < c.close_bucket_min_pos_error_m) bd = c.close_bucket_min_pos_error_m - pn;
-        else if (pn > c.close_bucket_max_pos_error_m) bd = pn - c.close_bucket_max_pos_error_m;
-        else bd = fmax(fmax(c.close_bucket_min_ori_error_rad - on, on - c.close_bucket_max_ori_error_rad), 0.0);
-        if (bd < best_dist) {
-          for (int k = 0; k < NJ; ++k) best_q[k] = cand[k];
-          have_best = true;
-          best_dist = bd;
-        }
-      }
-      if (!accepted) {
-        for (int k = 0; k < NJ; ++k) o.initial_q[k] = have_best ? best_q[k] : dclip(o.goal_q[k], s.lower[k], s.upper[k]);
-      }
-      return;
-    }
-    double d[NJ];
-    pcg_uniform_sym7(rng, c.init_q_noise, d);
-    for (int k = 0; k < NJ; ++k) o.initial_q[k] = dclip(o.goal_q[k] + d[k], s.lower[k], s.upper[k]);
-  } else {
-    if (s.rs.enabled && s.curriculum_enabled && s.n_stages > 0) {
-      sample_random_start_pair(s, rng, stage_index, o);
-      has_dq_pa = true;
-      return;
-    }
-    if (s.curriculum_enabled && s.n_stages > 0) {
-      int idx = sample_workspace_stage_index(s, rng, stage_index);
-      sample_stage_joint_target(s, rng, s.stages[idx].start_q, s.stages[idx].start_noise, o.initial_q);
-      sample_stage_joint_target(s, rng, s.stages[idx].goal_q, s.stages[idx].goal_noise, o.goal_q);
-      o.stage = idx;
-    } else {
-      sample_joint_configuration(s, rng, s.start_sample_margin_fraction, o.initial_q);
-      sample_joint_configuration(s, rng, s.goal_sample_margin_fraction, o.goal_q);
-    }
-  }
-}
-
-// reset() for one env.  Writes the state and returns the first observation in o[].
-template <typename R, int MODE>
-__device__ __forceinline__ void reset_env(const EnvState<R>& st, const DevCfg<R>& __restrict__ cfg, const DevSampler& __restrict__ smp,
-                                          const kp1_handoff_state* __restrict__ handoff, const ResetOptsDev& opts, int stage_index,
-                                          int64_t i, float* o) {
-  const int64_t n = st.n;
-  R q[NJ], dq[NJ], pa[NJ], goal_q[NJ], goal_pose[6], ee[6];
-  double q64[NJ], gq64[NJ];   // the kinematic chain is fp64 on both handles (DevCfg::Kin)
-  const bool given_q = (opts.flags & OPT_INITIAL_Q) != 0;
-  bool has_dq_pa = false, sampled_goal_pose = false, have_sample = false;
-  ResetSample rs;
-  Pcg rng;
-  bool rng_used = false;
-  if (given_q) {
-#pragma unroll
-    for (int k = 0; k < NJ; ++k) q64[k] = dclip(opts.initial_q[i * NJ + k], smp.lower[k], smp.upper[k]);
-  } else {
-    rng_load(st.rng64, st.rng32, n, i, rng);
-    rng_used = true;
-    sample_reset<MODE>(smp, handoff, rng, stage_index, rs, has_dq_pa, sampled_goal_pose);
-    have_sample = true;
-#pragma unroll
-    for (int k = 0; k < NJ; ++k) q64[k] = rs.initial_q[k];
-  }
-#pragma unroll
-  for (int k = 0; k < NJ; ++k) {
-    q[k] = (R)q64[k];
-    dq[k] = (opts.flags & OPT_INITIAL_DQ) ? (R)opts.initial_dq[i * NJ + k] : ((have_sample && has_dq_pa) ? (R)rs.initial_dq[k] : (R)0);
-    pa[k] = (opts.flags & OPT_INITIAL_PREV_ACTION) ? (R)opts.initial_prev_action[i * NJ + k]
-                                                   : ((have_sample && has_dq_pa) ? (R)rs.initial_prev_action[k] : (R)0);
-  }
-  fk_pose6_kin<R>(cfg.kin.fk, q64, ee);
-  if (opts.flags & OPT_GOAL_POSE6) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) goal_pose[k] = (R)opts.goal_pose6[i * 6 + k];
-#pragma unroll
-    for (int k = 0; k < NJ; ++k) goal_q[k] = (opts.flags & OPT_GOAL_Q) ? (R)opts.goal_q[i * NJ + k] : (R)0;
-  } else if (opts.flags & OPT_GOAL_Q) {
-#pragma unroll
-    for (int k = 0; k < NJ; ++k) {
-      gq64[k] = dclip(opts.goal_q[i * NJ + k], smp.lower[k], smp.upper[k]);
-      goal_q[k] = (R)gq64[k];
-    }
-    fk_pose6_kin<R>(cfg.kin.fk, gq64, goal_pose);
-  } else if (!given_q) {
-#pragma unroll
-    for (int k = 0; k < NJ; ++k) goal_q[k] = (R)rs.goal_q[k];
-    if (sampled_goal_pose) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) goal_pose[k] = (R)rs.goal_pose6[k];
-    } else {
-      fk_pose6_kin<R>(cfg.kin.fk, rs.goal_q, goal_pose);
-    }
-  } else {
-    // sample_reachable_target; KP1/kinematics/fk_interface.py:25-32
-    rng_load(st.rng64, st.rng32, n, i, rng);
-    rng_used = true;
-    double g[NJ];
-    sample_joint_configuration(smp, rng, smp.goal_sample_margin_fraction, g);
-#pragma unroll
-    for (int k = 0; k < NJ; ++k) goal_q[k] = (R)g[k];
-    fk_pose6_kin<R>(cfg.kin.fk, g, goal_pose);
-  }
-  if (rng_used) rng_store(st.rng64, st.rng32, n, i, rng);
-  R pe[3], oe[3], pn, on;
-  pose_error_norms<R>(ee, goal_pose, pe, oe, &pn, &on);
-#pragma unroll
-  for (int k = 0; k < NJ; ++k) {
-    st.q_store(k, i, q64[k]);
-    st.r(F_DQ + k, i) = dq[k];
-    st.r(F_PREV_ACTION + k, i) = pa[k];
-    st.r(F_GOAL_Q + k, i) = goal_q[k];
-  }
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    st.r(F_GOAL_POSE + k, i) = goal_pose[k];
-    st.r(F_EE_POSE + k, i) = ee[k];
-  }
-  // _capture_entry_metrics; arm_kinematic_env.py:425-430
-  st.r(F_ENTRY + 0, i) = pn;
-  st.r(F_ENTRY + 1, i) = on;
-  st.r(F_ENTRY + 2, i) = norm7<R>(pa);
-  st.r(F_ENTRY + 3, i) = norm7<R>(dq);
-  st.r(F_MIN_POS, i) = std::numeric_limits<R>::infinity();
-  st.r(F_POS_ERR, i) = pn;
-  st.r(F_ORI_ERR, i) = on;
-  st.r(F_EXEC_DQ, i) = (R)0;
-  st.r(F_ACTION_L2, i) = (R)0;
-  st.r(F_DQ_CHANGE, i) = (R)0;
-  st.iv(I_STEP, i) = 0;
-  st.iv(I_DWELL, i) = 0;
-  st.iv(I_ENTRY, i) = 0;
-  st.iv(I_DRIFT, i) = 0;
-  st.iv(I_FLAGS, i) = 0;
-  st.iv(I_STAGE, i) = have_sample ? rs.stage : stage_index;
-  build_observation<R>(cfg, MODE, q, dq, pa, pe, oe, 0, 0, o);
-}
-
-template <typename R>
-struct StepArgs {
-  EnvState<R> st;
-  const DevCfg<R>* cfg;
-  const DevSampler* smp;
-  const kp1_handoff_state* handoff;
-  const R* actions;      // [N][7]
-  float* obs;            // [N][56]
-  R* reward;             // [N]
-  uint8_t* done;         // [N]
-  float* terminal_obs;   // [N][56] or nullptr
-  R* comps;              // [n_components][N] or nullptr
-  int auto_reset;
-  int stage_index;
-  int obs_stride;
-  const int32_t* stage_ptr;  // device-resident curriculum stage (kp1_bind_stage_ptr) or nullptr
-};
-
-#ifndef KP1_STEP_MIN_WAVES
-#define KP1_STEP_MIN_WAVES 1   // minimum waves per SIMD the register allocation must leave room for (launch_bounds' second argument)
-#endif
-// One env step of lane i, auto-reset of a finished env included (VecEnv semantics).
-// [round 3, measured and removed] A split form for large batches -- this body without the reset branch under launch_bounds(256, 2), i.e. two
-// waves per SIMD instead of one, plus a second kernel that resets the finished envs -- is bit-identical and NOT faster: 116.9 us for the step
-// kernel alone at 524288 envs against 116-120 us fused (profiles/r03_ab_env_split_step.log).  Occupancy is not what bounds the large-batch
-// rate; the 110 dword-per-lane accesses of a step are (each wave instruction touches 256 bytes of a different 2 MB plane): DESIGN.md 4.5.
-template <typename R, int MODE, bool COMPS>
-__device__ __forceinline__ void step_env_lane(const StepArgs<R>& a, const int64_t i) {
-  const int64_t n = a.st.n;
-  KP1_ETR(0)
-#ifndef KP1_CFG_VEC
-#define KP1_CFG_VEC 0     // 0: config through scalar loads; 1: the FK constants through lane_view; 2: the whole block through lane_view
-#endif
-#if KP1_CFG_VEC == 2
-  const DevCfg<R>& __restrict__ cfg = lane_view(*a.cfg);
-  const DevFk<double>& __restrict__ fkc = cfg.kin.fk;
-#elif KP1_CFG_VEC == 1
-  const DevCfg<R>& __restrict__ cfg = *scalar_cache_warm(a.cfg);
-  const DevFk<double>& __restrict__ fkc = lane_view(cfg.kin.fk);
-#else
-  const DevCfg<R>& __restrict__ cfg = *scalar_cache_warm(a.cfg);
-  const DevFk<double>& __restrict__ fkc = cfg.kin.fk;
-#endif
-  KP1_ETR(1)
-  const EnvState<R>& st = a.st;
-  const R Z = (R)0;
-
-  R act[NJ], dq[NJ], prev_action[NJ], goal[6], ee[6];
-  double q[NJ];   // fp64 kinematic chain (DevCfg::Kin)
-#pragma unroll
-  for (int k = 0; k < NJ; ++k) {
-    act[k] = kp_clip<R>(a.actions[i * NJ + k], (R)-1, (R)1);  // :214
-    q[k] = st.q_load(k, i);
-    dq[k] = st.r(F_DQ + k, i);
-    prev_action[k] = st.r(F_PREV_ACTION + k, i);
-  }
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    goal[k] = st.r(F_GOAL_POSE + k, i);
-    ee[k] = st.r(F_EE_POSE + k, i);
-  }
-  int episode_step = st.iv(I_STEP, i), dwell = st.iv(I_DWELL, i), entry_count = st.iv(I_ENTRY, i), drift_count = st.iv(I_DRIFT, i);
-  int flags = st.iv(I_FLAGS, i);
-  R min_pos = st.r(F_MIN_POS, i);
-
-  R pe[3], oe[3], prev_pos, prev_ori;
-  pose_error_norms<R>(ee, goal, pe, oe, &prev_pos, &prev_ori);  // :219-221
-  KP1_ETR_PIN(2, prev_pos, prev_ori)
-
-  R dyn_limit = kp_clip<R>(cfg.env.dock_residual_action_limit, Z, (R)1);
-  R dyn_dqc = kp_max<R>(cfg.env.dock_delta_q_change_limit_scale, Z);
-  if constexpr (MODE == KP1_MODE_DOCK) {  // :224-228, 508-528
-    dyn_limit = kp_clip<R>(interpolate_control<R>(prev_pos, cfg.env.dock_dynamic_action_limit_near_pos_threshold_m,
-                                                  cfg.env.dock_dynamic_action_limit_far_pos_threshold_m,
-                                                  cfg.env.dock_dynamic_residual_action_limit_near,
-                                                  cfg.env.dock_dynamic_residual_action_limit_far, cfg.env.dock_residual_action_limit), Z, (R)1);
-    dyn_dqc = kp_max<R>(interpolate_control<R>(prev_pos, cfg.env.dock_dynamic_action_limit_near_pos_threshold_m,
-                                               cfg.env.dock_dynamic_action_limit_far_pos_threshold_m,
-                                               cfg.env.dock_dynamic_delta_q_change_limit_scale_near,
-                                               cfg.env.dock_dynamic_delta_q_change_limit_scale_far, cfg.env.dock_delta_q_change_limit_scale), Z);
-#pragma unroll
-    for (int k = 0; k < NJ; ++k) act[k] = kp_clip<R>(act[k], -dyn_limit, dyn_limit);
-  }
-  const bool prev_in_near = is_near_goal<R>(cfg, prev_pos, prev_ori);  // :231
-  double scale = cfg.kin.action_delta_scale;                           // :232-236
-  if constexpr (MODE == KP1_MODE_DOCK) {
-    if (cfg.kin.dock_action_delta_scale > 0.0) scale = cfg.kin.dock_action_delta_scale;
-  } else {
-    if (cfg.env.dynamic_action_delta_scale_enabled) {  // :530-542
-      R mult = interpolate_control<R>(prev_pos, cfg.env.dynamic_action_delta_scale_near_pos_threshold_m,
-                                      cfg.env.dynamic_action_delta_scale_far_pos_threshold_m,
-                                      cfg.env.dynamic_action_delta_scale_near_multiplier,
-                                      cfg.env.dynamic_action_delta_scale_far_multiplier, (R)1);
-      scale = cfg.kin.action_delta_scale * (double)kp_max<R>(mult, Z);
-    }
-  }
-  R q_next[NJ], dq_next[NJ];
-  double q_next64[NJ];
-  R dq_change_ss = Z, dq_ss = Z, prev_dq_ss = Z, act_ss = Z, pact_ss = Z, dact_ss = Z, margin_min = (R)1;
-#pragma unroll
-  for (int k = 0; k < NJ; ++k) {
-    const double max_dq = cfg.kin.dlim[k] * scale;   // :237
-    double cmd = (double)act[k] * max_dq;            // :238
-    if constexpr (MODE == KP1_MODE_DOCK) {           // :239-242
-      if (dyn_dqc > Z) {
-        const double lim = max_dq * (double)dyn_dqc, dqk = (double)dq[k];
-        cmd = dqk + dclip(cmd - dqk, -lim, lim);
-        cmd = dclip(cmd, -max_dq, max_dq);
-      }
-    }
-    q_next64[k] = joint_clip<double>(q[k] + cmd, cfg.kin.lower[k], cfg.kin.upper[k]);  // :243
-    q_next[k] = (R)q_next64[k];
-    dq_next[k] = (R)(q_next64[k] - q[k]);                                             // :244
-    R dd = dq_next[k] - dq[k];
-    dq_change_ss += dd * dd;
-    dq_ss += dq_next[k] * dq_next[k];
-    prev_dq_ss += dq[k] * dq[k];
-    act_ss += act[k] * act[k];
-    pact_ss += prev_action[k] * prev_action[k];
-    R da = act[k] - prev_action[k];
-    dact_ss += da * da;
-    margin_min = kp_min<R>(margin_min, joint_limit_margin<R>(q_next[k], cfg.lower[k], cfg.upper[k]));  // joint_limits.py:166-174
-  }
-  KP1_ETR_PIN(3, q_next64[0], q_next64[1], q_next64[2], q_next64[3], q_next64[4], q_next64[5], q_next64[6], (double)margin_min, (double)dq_change_ss)
-  R ee_next[6];
-  fk_pose6_kin<R>(fkc, q_next64, ee_next);  // :246
-  KP1_ETR_PIN(4, ee_next[0], ee_next[1], ee_next[2], ee_next[3], ee_next[4], ee_next[5])
-  R curr_pos, curr_ori;
-  pose_error_norms<R>(ee_next, goal, pe, oe, &curr_pos, &curr_ori);  // :248-250
-  const bool curr_pre = is_pre_near_goal<R>(cfg, curr_pos, curr_ori);
-  const bool curr_near = is_near_goal<R>(cfg, curr_pos, curr_ori);
-  min_pos = curr_pos < min_pos ? curr_pos : min_pos;  // python min(a, b): a NaN b keeps a (:251)
-  if (curr_pre) flags |= FLAG_PRE_NEAR_HIT;
-  if (curr_near && !prev_in_near) entry_count += 1;
-  dwell = curr_near ? dwell + 1 : 0;
-  if (prev_in_near && curr_pos > prev_pos) drift_count += 1;
-
-  // evaluate_termination; KP1/envs/termination.py:20-57
-  const int step_count = episode_step + 1;
-  bool terminated = false, truncated = false, success = false, invalid = false;
-  const bool criteria = curr_pos <= cfg.term.success_pos_threshold_m &&
-                        (!cfg.term.require_orientation || curr_ori <= cfg.term.success_ori_threshold_rad) &&
-                        dwell >= cfg.term.success_dwell_steps;
-  if (!kp_isfinite(curr_pos) || !kp_isfinite(curr_ori)) {
-    terminated = true;
-    invalid = true;
-  } else if (criteria) {
-    success = true;
-    if (cfg.term.terminate_on_success) terminated = true;
-  }
-  if (!terminated && step_count >= cfg.term.max_episode_steps) truncated = true;
-
-  KP1_ETR_PIN(5, curr_pos, curr_ori, (R)dwell, (R)(terminated ? 1 : 0), (R)(truncated ? 1 : 0))
-  RewardIn<R> ri;
-  ri.prev_pos = prev_pos; ri.curr_pos = curr_pos; ri.prev_ori = prev_ori; ri.curr_ori = curr_ori;
-  ri.action_norm = kp_sqrt(act_ss); ri.prev_action_norm = kp_sqrt(pact_ss);
-  ri.action_msq = kp_div(act_ss, (R)7); ri.action_delta_msq = kp_div(dact_ss, (R)7);
-  ri.dq_norm = kp_sqrt(dq_ss); ri.prev_dq_norm = kp_sqrt(prev_dq_ss); ri.dq_change_l2 = kp_sqrt(dq_change_ss);
-  ri.margin_min = margin_min;
-  ri.dwell = dwell; ri.entry_count = entry_count; ri.drift_count = drift_count;
-  ri.pre = curr_pre; ri.cn = curr_near; ri.pn = prev_in_near; ri.success = success;
-  R reward;
-  if constexpr (MODE == KP1_MODE_DOCK) {
-    ri.entry_pos = st.r(F_ENTRY + 0, i); ri.entry_ori = st.r(F_ENTRY + 1, i);
-    ri.entry_action = st.r(F_ENTRY + 2, i); ri.entry_dq = st.r(F_ENTRY + 3, i);
-    reward = dock_reward<R, COMPS>(cfg.dock, ri, COMPS ? a.comps + i : nullptr, n);
-  } else {
-    ri.entry_pos = ri.entry_ori = ri.entry_action = ri.entry_dq = Z;
-    reward = approach_reward<R, COMPS>(cfg.reward, ri, COMPS ? a.comps + i : nullptr, n);
-  }
-  KP1_ETR_PIN(6, reward)
-  episode_step += 1;  // :344
-  if (curr_near) flags |= FLAG_NEAR_HIT;
-  flags = success ? (flags | FLAG_SUCCESS) : (flags & ~FLAG_SUCCESS);
-
-  float o[KP1_OBS_DIM];
-  build_observation<R>(cfg, MODE, q_next, dq_next, act, pe, oe, episode_step, dwell, o);
-  KP1_ETR_PIN(7, o[0], o[7], o[14], o[21], o[28], o[31], o[34], o[40], o[54], o[55], o[6], o[13], o[20], o[27])
-  a.reward[i] = reward;
-  const bool done = terminated || truncated;
-  a.done[i] = (uint8_t)((terminated ? KP1_DONE_TERMINATED : 0) | (truncated ? KP1_DONE_TRUNCATED : 0) |
-                        (success ? KP1_DONE_SUCCESS : 0) | (invalid ? KP1_DONE_INVALID : 0));
-  if (done && a.auto_reset) {
-    // VecEnv auto-reset: keep the finished episode's last observation + info norms, then reset in place.
-    if (a.terminal_obs) store_obs_row(a.terminal_obs, i, o, a.obs_stride);
-    ResetOptsDev none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    int stage = a.stage_index;
-    const DevSampler& smp = uniform_block(a.smp);
-    if (a.stage_ptr) stage = kp_clipi(*a.stage_ptr, 0, kp_maxi(smp.n_stages - 1, 0));
-    reset_env<R, MODE>(st, cfg, smp, a.handoff, none, stage, i, o);
-    // info of the finished episode stays readable (SB3 infos[i] of a done env is the terminal info)
-    st.r(F_POS_ERR, i) = curr_pos;
-    st.r(F_ORI_ERR, i) = curr_ori;
-    st.r(F_EXEC_DQ, i) = ri.dq_norm;
-    st.r(F_ACTION_L2, i) = ri.action_norm;
-    st.r(F_DQ_CHANGE, i) = ri.dq_change_l2;
-    st.iv(I_FLAGS, i) = (flags & FLAG_SUCCESS);  // success of the finished episode; hit flags are the new episode's (0)
-  } else {
-#pragma unroll
-    for (int k = 0; k < NJ; ++k) {
-      st.q_store(k, i, q_next64[k]);
-      st.r(F_DQ + k, i) = dq_next[k];
-      st.r(F_PREV_ACTION + k, i) = act[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) st.r(F_EE_POSE + k, i) = ee_next[k];
-    st.r(F_MIN_POS, i) = min_pos;
-    st.r(F_POS_ERR, i) = curr_pos;
-    st.r(F_ORI_ERR, i) = curr_ori;
-    st.r(F_EXEC_DQ, i) = ri.dq_norm;
-    st.r(F_ACTION_L2, i) = ri.action_norm;
-    st.r(F_DQ_CHANGE, i) = ri.dq_change_l2;
-    st.iv(I_STEP, i) = episode_step;
-    st.iv(I_DWELL, i) = dwell;
-    st.iv(I_ENTRY, i) = entry_count;
-    st.iv(I_DRIFT, i) = drift_count;
-    st.iv(I_FLAGS, i) = flags;
-  }
-  store_obs_row(a.obs, i, o, a.obs_stride);
-  KP1_ETR(8)
-#ifdef KP1_ENV_TRACE
-  __builtin_amdgcn_s_waitcnt(0);   // every store of this wave acknowledged
-  KP1_ETR(9)
-#endif
-}
+#include "kp1_env_step.inc"
 
 template <typename R, int MODE, bool COMPS>
 __global__ void __launch_bounds__(256, KP1_STEP_MIN_WAVES) kp1_step_kernel(const StepArgs<R> a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.st.n) return;
-  step_env_lane<R, MODE, COMPS>(a, i);
+  step_env_lane<R, MODE, COMPS>(a, i, a.actions + i * NJ);
 }
 
 template <typename R, int MODE>
@@ -961,7 +485,7 @@ int seed_streams(kp1_env* e, uint64_t seed0, uint64_t first_env_id) {
 }
 
 template <typename R>
-int launch_step(kp1_env* e, const void* actions, float* obs, void* reward, uint8_t* done, float* terminal_obs, int auto_reset) {
+StepArgs<R> make_step_args(kp1_env* e, const void* actions, float* obs, void* reward, uint8_t* done, float* terminal_obs, int auto_reset) {
   StepArgs<R> a;
   a.st = state_of<R>(e);
   a.cfg = (const DevCfg<R>*)e->dev_cfg;
@@ -977,6 +501,12 @@ int launch_step(kp1_env* e, const void* actions, float* obs, void* reward, uint8
   a.stage_index = e->stage;
   a.obs_stride = e->obs_stride;
   a.stage_ptr = e->cfg.curriculum_enabled ? e->stage_ptr : nullptr;
+  return a;
+}
+
+template <typename R>
+int launch_step(kp1_env* e, const void* actions, float* obs, void* reward, uint8_t* done, float* terminal_obs, int auto_reset) {
+  const StepArgs<R> a = make_step_args<R>(e, actions, obs, reward, done, terminal_obs, auto_reset);
   const int block = block_for(e->n);
   const dim3 grid((unsigned)((e->n + block - 1) / block));
   const bool comps = e->comps_enabled && e->comps;
@@ -1094,6 +624,22 @@ int ensure_scratch(kp1_env* e) {
 // ============================================================================================
 // C ABI
 // ============================================================================================
+namespace kp1 {
+int env_step_args_f32(kp1_env* e, void* out, size_t out_bytes, const void* actions, float* obs, void* reward, uint8_t* done, float* terminal_obs,
+                      int auto_reset, int* mode, int64_t* n_envs, int* device) {
+  if (!e || !out) return fail(KP1_ERR_INVALID, "NULL argument");
+  if (e->real_type != KP1_REAL_F32) return fail(KP1_ERR_UNSUPPORTED, "the fused policy + env step runs on the fp32 handle");
+  if (e->comps_enabled && e->comps) return fail(KP1_ERR_UNSUPPORTED, "the fused policy + env step does not record reward components");
+  if (out_bytes != sizeof(StepArgs<float>)) return fail(KP1_ERR_INVALID, "StepArgs<float> layout mismatch between translation units");
+  const StepArgs<float> a = make_step_args<float>(e, actions, obs, reward, done, terminal_obs, auto_reset);
+  std::memcpy(out, &a, sizeof a);
+  *mode = e->mode;
+  *n_envs = e->n;
+  *device = e->device;
+  return KP1_OK;
+}
+}  // namespace kp1
+
 extern "C" {
 
 const char* kp1_last_error(void) { return g_last_error.c_str(); }

@@ -45,6 +45,10 @@ inline hipError_t launch_status() {
   if (e == hipSuccess && sync_check_enabled()) e = hipDeviceSynchronize();
   return e;
 }
+// kp1_env.hip -> kp1_mlp.hip: the kernel-argument block of one fp32 env step (StepArgs<float> of kp1_env_step.inc, copied into `out`), for the
+// rollout kernel that runs the policy forward and the env step in one launch.  Fails for fp64 handles and while reward components are on.
+int env_step_args_f32(kp1_env* env, void* out, size_t out_bytes, const void* actions, float* obs, void* reward, uint8_t* done, float* terminal_obs,
+                      int auto_reset, int* mode, int64_t* n_envs, int* device);
 }  // namespace kp1
 
 #define HIP_TRY(expr)                                                                                              \

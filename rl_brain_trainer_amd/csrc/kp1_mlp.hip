@@ -20,9 +20,11 @@
 #include <vector>
 
 #include "../../include/kp1_ppo.h"
+#include "kp1_device.hpp"
 #include "kp1_host.hpp"
 
 using kp1::fail;
+using namespace kp1;   // kp1_device.hpp: the env arithmetic the rollout kernel steps its tile's envs with
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: arrays of it are reliably scalar-replaced (HIP's float4 struct was not)
@@ -1148,6 +1150,7 @@ __global__ void __launch_bounds__(KP1_ADAM_BLOCK) adam_kernel(float* __restrict_
   }
 }
 
+#include "kp1_env_step.inc"
 #include "kp1_mlp_tile.inc"
 #include "kp1_mlp_fused.inc"
 
@@ -1300,6 +1303,21 @@ int launch_fused(const FusedArgs& fa_in, hipStream_t stream) {
   } else {
     HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     hipLaunchKernelGGL((mlp_tile_kernel<true, 4>), grid, dim3(G::NTH), bytes, stream, fa);
+  }
+  return KP1_OK;
+}
+
+// policy forward + env step in one launch (kp1_mlp_forward_env_step): env_mode = KP1_MODE_APPROACH / KP1_MODE_DOCK, 64-float observation rows
+int launch_fused_infer_env(const FusedArgs& fa, int env_mode, hipStream_t stream) {
+  using G = FuGeom<false>;
+  const size_t bytes = sizeof(float) * G::LDS_FLOATS;
+  const dim3 grid((fa.n + G::BM - 1) / G::BM, 1, fa.value ? 2 : 1);
+  if (env_mode == KP1_MODE_DOCK) {
+    HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL((mlp_tile_kernel<false, 2, 2>), grid, dim3(G::NTH), bytes, stream, fa);
+  } else {
+    HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL((mlp_tile_kernel<false, 2, 1>), grid, dim3(G::NTH), bytes, stream, fa);
   }
   return KP1_OK;
 }
@@ -1541,6 +1559,30 @@ int kp1_mlp_forward(kp1_mlp* m, const float* obs, int32_t obs_stride, int32_t n,
   a.w3 = m->k.w3; a.b3 = m->k.b3; a.log_std = m->k.log_std;
   a.noise = noise; a.mean = mean; a.value = value; a.action = action; a.clipped = clipped_action; a.log_prob = log_prob;
   hipLaunchKernelGGL(head_infer_kernel, dim3((n + HEAD_ROWS - 1) / HEAD_ROWS), dim3(256), sizeof(float) * HEADS * m->Hp, (hipStream_t)stream, a);
+  HIP_TRY(kp1::launch_status());
+  return KP1_OK;
+}
+
+int kp1_mlp_forward_env_step(kp1_mlp* m, kp1_env* env, const float* obs, int32_t obs_stride, const float* noise, float* value, float* action,
+                             float* log_prob, float* next_obs, float* reward, uint8_t* done, float* terminal_obs, void* stream) {
+  if (!m || !env || !obs || !action || !next_obs || !reward || !done) return fail(KP1_ERR_INVALID, "NULL argument to kp1_mlp_forward_env_step");
+  if (!(m->fused && m->Hp == FU_HP) || m->L.INP != 64)
+    return fail(KP1_ERR_UNSUPPORTED, "kp1_mlp_forward_env_step needs the 2x256 tile kernels and the 56-float observation (padded to 64)");
+  if (obs_stride != m->L.IN && obs_stride != m->L.INP) return fail(KP1_ERR_INVALID, "obs_stride must be 56 or 64");
+  int rc = mlp_check_device(m);
+  if (rc != KP1_OK) return rc;
+  FusedArgs fa{};
+  int mode = 0, device = 0;
+  int64_t n_envs = 0;
+  rc = kp1::env_step_args_f32(env, &fa.env, sizeof fa.env, nullptr, next_obs, reward, done, terminal_obs, 1, &mode, &n_envs, &device);
+  if (rc != KP1_OK) return rc;
+  if (device != m->device) return fail(KP1_ERR_INVALID, "the env handle and the MLP workspace live on different devices");
+  if (n_envs > m->max_batch) return fail(KP1_ERR_INVALID, "more envs than the workspace max_batch");
+  fa.obs = obs; fa.obs_stride = obs_stride; fa.Kreal = obs_stride >= m->L.INP ? m->L.INP : m->L.IN; fa.inp = m->L.INP; fa.idx = nullptr; fa.n = (int)n_envs;
+  fa.k = m->k;
+  fa.noise = noise; fa.value = value; fa.action = action; fa.log_prob = log_prob;
+  rc = launch_fused_infer_env(fa, mode, (hipStream_t)stream);
+  if (rc != KP1_OK) return rc;
   HIP_TRY(kp1::launch_status());
   return KP1_OK;
 }

@@ -25,6 +25,7 @@ class MlpKernels:
         L.kp1_mlp_num_params_ex.restype = C.c_int64
         L.kp1_mlp_pack_weights.argtypes = [vp, vp, vp]
         L.kp1_mlp_forward.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+        L.kp1_mlp_forward_env_step.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.kp1_mlp_loss_grad.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, f32, f32, vp, f32, f32, f32, f32, vp, vp, i32, vp]
         L.kp1_mlp_adam_step.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, i32, i32, vp]
         L.kp1_mlp_time_kernels.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
@@ -88,6 +89,13 @@ class MlpKernels:
         n, stride = obs.shape[0], obs.shape[1]
         assert obs.is_contiguous() and obs.dtype == torch.float32
         native.check(self.L.kp1_mlp_forward(self._h, _p(obs), stride, n, _p(noise), _p(mean), _p(value), _p(action), _p(clipped), _p(log_prob), self._stream()))
+
+    def forward_env_step(self, env, obs: torch.Tensor, *, noise, value, action, log_prob, next_obs, reward, done, terminal_obs) -> None:
+        """One rollout step in one launch (kp1_mlp_forward_env_step): policy.forward on `obs` (row m = env m of `env`, an fp32
+        ArmKinematicVecEnv), sampling, and VecEnv.step of every env with auto-reset, written into the caller's rollout buffers."""
+        assert obs.is_contiguous() and obs.dtype == torch.float32 and obs.shape[0] == env.n_envs
+        native.check(self.L.kp1_mlp_forward_env_step(self._h, env._handle, _p(obs), obs.shape[1], _p(noise), _p(value), _p(action), _p(log_prob),
+                                                     _p(next_obs), _p(reward), _p(done), _p(terminal_obs), self._stream()))
 
     def mean_value(self, obs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         n = obs.shape[0]

@@ -425,6 +425,11 @@ class PPO:
 
             self.done_chunk = math.gcd(T, max(int(_os.environ.get("KP1_DONE_EXCHANGE_STEPS", "16")), 1))
             self._done_gather = torch.zeros((self.dist.world_size, self.done_chunk, N), dtype=torch.uint8, device=dev)
+        # one launch per rollout step for policy forward + env step where the env is the plain fp32 vectorised env and the tile kernels run
+        # (KP1_FUSED_ROLLOUT=0: the two-launch form, kept as the A/B and test reference)
+        self._fused_env_step = bool(backend == "hip" and type(env) is ArmKinematicVecEnv and env.dtype == torch.float32 and cfg.hidden == 256
+                                    and self.obs_dim <= 64 and not getattr(env, "_reward_components_on", False)
+                                    and os.environ.get("KP1_FUSED_ROLLOUT", "1") != "0")
         # optional host hook after every env step (done bits of that step, device tensor): what SB3 callbacks' _on_step sees.
         # Setting it makes the rollout eager (a host hook cannot live inside a hipGraph replay).
         self.step_callback = None
@@ -612,9 +617,10 @@ class PPO:
             self._replay_checked("rollout", self._rollout_graph)
         for t in range(0 if not graph_rollout else T, T):
             if self._mlp is not None:
-                # 3 launches: two MFMA layer GEMMs + the head kernel (heads, sampling, log-prob, clip fused)
-                self._mlp.forward(self.obs_buf[t], noise=self.noise_all[t], value=self.val_buf[t], action=self.act_buf[t],
-                                  clipped=self.clip_act, log_prob=self.logp_buf[t])
+                self._rollout_step_hip(t)      # the launch sequence the captured rollout replays
+                if self.step_callback is not None:
+                    self.step_callback(self.done_buf[t])
+                continue
             else:
                 mean, value = self._forward(self.obs_buf[t])
                 noise = torch.randn((N, ACT_DIM), dtype=torch.float32, device=self.device, generator=self.gen)
@@ -655,10 +661,19 @@ class PPO:
     def _rollout_step_hip(self, t: int) -> None:
         # (running the tracker on a side stream under the next policy forward was measured: the fork / join inside the graph
         # cost more than the 4 us kernel it hid -- 7.4 ms vs 5.9 ms per 128-step rollout)
-        self._mlp.forward(self.obs_buf[t], noise=self.noise_all[t], value=self.val_buf[t], action=self.act_buf[t],
-                          clipped=self.clip_act, log_prob=self.logp_buf[t])
-        self.env.step_into(self.clip_act, self.obs_buf[t + 1], self.rew_buf[t], self.done_buf[t], self.term_obs_buf[t], True)
+        self._policy_env_step(t)
         self._curriculum_observe(t)
+
+    def _policy_env_step(self, t: int) -> None:
+        if self._fused_env_step:
+            # policy forward + sampling + env step (auto-reset included) in ONE launch: the tile's policy workgroup steps its 32 envs itself
+            self._mlp.forward_env_step(self.env, self.obs_buf[t], noise=self.noise_all[t], value=self.val_buf[t], action=self.act_buf[t],
+                                       log_prob=self.logp_buf[t], next_obs=self.obs_buf[t + 1], reward=self.rew_buf[t], done=self.done_buf[t],
+                                       terminal_obs=self.term_obs_buf[t])
+        else:
+            self._mlp.forward(self.obs_buf[t], noise=self.noise_all[t], value=self.val_buf[t], action=self.act_buf[t],
+                              clipped=self.clip_act, log_prob=self.logp_buf[t])
+            self.env.step_into(self.clip_act, self.obs_buf[t + 1], self.rew_buf[t], self.done_buf[t], self.term_obs_buf[t], True)
 
     def _capture_rollout(self) -> None:
         """Record the T-step rollout (policy forward, env step, curriculum tracker; data parallel: the done-byte all-gather of every chunk)
@@ -675,9 +690,7 @@ class PPO:
                 self.env.use_current_stream()
                 if can_snapshot:
                     self.env.snapshot()      # the warm-up step below must not move the episodes or the random streams
-                self._mlp.forward(self.obs_buf[0], noise=self.noise_all[0], value=self.val_buf[0], action=self.act_buf[0],
-                                  clipped=self.clip_act, log_prob=self.logp_buf[0])
-                self.env.step_into(self.clip_act, self.obs_buf[1], self.rew_buf[0], self.done_buf[0], self.term_obs_buf[0], True)
+                self._policy_env_step(0)
                 if self.curriculum is not None:
                     self.curriculum.observe(self.done_buf[0].zero_(), 0)   # also loads the module the chunk form of the tracker lives in
                 self._post_rollout()                                        # the graph's tail, once eagerly (its buffers are rewritten by the real rollout)

@@ -255,6 +255,7 @@ class ArmKinematicVecEnv:
 
     def enable_reward_components(self, enable: bool = True) -> None:
         native.check(self.L.kp1_enable_reward_components(self._handle, int(enable)))
+        self._reward_components_on = bool(enable)
         self._components = bool(enable)
         self.launch_args_version += 1
 

@@ -11,9 +11,11 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import load_golden_config
 from rl_brain_trainer_amd import ppo as P
 from rl_brain_trainer_amd.curriculum import PointCurriculum
 from rl_brain_trainer_amd.mlp import MlpKernels
+from rl_brain_trainer_amd.vec_env import ArmKinematicVecEnv
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
@@ -554,3 +556,41 @@ def test_loss_grad_advantage_modes(mode):
         assert (gk - gr).abs().max().item() <= 2e-4 * scale + 1e-7, (mode, name)
         off += cnt
     k.close()
+
+
+@pytest.mark.parametrize("cfg_name,stage,n_envs,n_steps", [("workspace_expansion_bigtrain", 5, 1000, 100),
+                                                           ("dock_workspace_handoff_noop_ft_12env_raw", 0, 320, 80)])
+def test_fused_policy_env_step_equals_two_launches(cfg_name, stage, n_envs, n_steps, monkeypatch):
+    """kp1_mlp_forward_env_step (policy forward, sampling and the env step of a 32-row tile in ONE launch: mlp_tile_kernel<false, 2, ENV>)
+    against kp1_mlp_forward + kp1_step on identical seeds: a whole rollout with auto-resets -- observations, actions, log-probs, values,
+    rewards, done bytes, terminal observations, advantages, every env state field and all PCG64 streams bit for bit.  1000 / 320 envs: the
+    last tile is ragged (rows >= n are masked out of the env step)."""
+    cfg = load_golden_config(cfg_name)
+    out = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("KP1_FUSED_ROLLOUT", form)
+        env = ArmKinematicVecEnv(cfg, n_envs, seed=21, real="f32")
+        env.set_curriculum_stage(stage)
+        cur = PointCurriculum(success_rate_threshold=0.0, window_episodes=8, min_episodes_per_stage=8, max_stage_index=11, initial_stage_index=stage) \
+            if cfg.c.curriculum_enabled else None
+        ppo = P.PPO(env, P.PPOConfig(n_steps=n_steps, batch_size=n_envs * n_steps // 4, n_epochs=1, hidden=256, learning_rate=3e-4, seed=5), curriculum=cur,
+                    backend="hip")
+        assert ppo._fused_env_step == (form == "1") and ppo.use_graphs
+        bufs = []
+        for _ in range(2):                       # the first rollout captures (warm-up between snapshot and restore), the second replays
+            ppo.collect_rollouts()
+            torch.cuda.synchronize()
+            bufs.append({k: getattr(ppo, k).clone() for k in ("obs_buf", "act_buf", "logp_buf", "val_buf", "rew_buf", "done_buf", "term_obs_buf", "adv_buf")})
+        info = {k: v.clone() for k, v in env.info().items()}
+        out[form] = (bufs, info, env.rng_state(), None if cur is None else cur.read().stage_index)
+        if cur is not None:
+            cur.close()
+        env.close()
+    (b1, i1, r1, s1), (b0, i0, r0, s0) = out["1"], out["0"]
+    assert int((b0[1]["done_buf"] & 3 != 0).sum()) + int((b0[0]["done_buf"] & 3 != 0).sum()) >= n_envs      # auto-resets happened
+    for x, y in zip(b1, b0):
+        for k in x:
+            assert torch.equal(x[k], y[k]), k
+    for k in i0:
+        assert torch.equal(i1[k], i0[k]), k
+    assert np.array_equal(r1, r0) and s1 == s0
