@@ -35,6 +35,7 @@ from typing import Any
 import torch
 
 from . import config as kcfg
+from . import sb3_pickle as sbp
 
 SB3_VERSION_PIN = "2.8.0"
 
@@ -49,20 +50,24 @@ def _policy_data(ppo, env_cfg: kcfg.EnvConfig | None) -> dict[str, Any]:
         layout = rcfg.ROUTE_OBS_LAYOUT
     obs_space = {k: {"shape": [n], "low": (0.0 if k in ("task_type", "mode_flag", "progress", "joint_limit_margin", "route_scalar") else -1.0), "high": 1.0,
                      "dtype": "float32"} for k, (_, n) in layout.items()}
+    # the six members SB3 restores by unpickling: pickle streams assembled without gymnasium / SB3 (sb3_pickle.py; PARITY UNPINNED, see there)
+    obs_pickle = sbp.serialized(sbp.dict_space({k: sbp.box(v["low"], v["high"], v["shape"][0]) for k, v in obs_space.items()}))
     return {
         "policy_class": {":type:": "<class 'abc.ABCMeta'>", "__module__": "stable_baselines3.common.policies",
-                         "__name__": "MultiInputActorCriticPolicy", ":serialized:": None},
+                         "__name__": "MultiInputActorCriticPolicy", ":serialized:": sbp.serialized(sbp.POLICY_CLASS)},
         "policy_kwargs": {} if H == 64 else {"net_arch": {"pi": [H, H], "vf": [H, H]}},
-        "observation_space": {":type:": "<class 'gymnasium.spaces.dict.Dict'>", ":serialized:": None, "spaces": obs_space},
-        "action_space": {":type:": "<class 'gymnasium.spaces.box.Box'>", ":serialized:": None, "shape": [kcfg.NJ], "low": -1.0, "high": 1.0,
-                         "dtype": "float32"},
+        "observation_space": {":type:": "<class 'gymnasium.spaces.dict.Dict'>", ":serialized:": obs_pickle, "spaces": obs_space},
+        "action_space": {":type:": "<class 'gymnasium.spaces.box.Box'>", ":serialized:": sbp.serialized(sbp.box(-1.0, 1.0, kcfg.NJ)), "shape": [kcfg.NJ],
+                         "low": -1.0, "high": 1.0, "dtype": "float32"},
         "n_envs": int(ppo.n_envs * ppo.dist.world_size),
         "num_timesteps": int(ppo.num_timesteps),
         "_total_timesteps": int(cfg.total_timesteps),
         "seed": int(cfg.seed),
         "learning_rate": float(cfg.learning_rate),
-        "lr_schedule": {":type:": "<class 'stable_baselines3.common.utils.FloatSchedule'>", ":serialized:": None, "value": float(cfg.learning_rate)},
-        "clip_range": {":type:": "<class 'stable_baselines3.common.utils.FloatSchedule'>", ":serialized:": None, "value": float(cfg.clip_range)},
+        "lr_schedule": {":type:": "<class 'stable_baselines3.common.utils.FloatSchedule'>", ":serialized:": sbp.serialized(sbp.float_schedule(cfg.learning_rate)),
+                        "value": float(cfg.learning_rate)},
+        "clip_range": {":type:": "<class 'stable_baselines3.common.utils.FloatSchedule'>", ":serialized:": sbp.serialized(sbp.float_schedule(cfg.clip_range)),
+                       "value": float(cfg.clip_range)},
         "n_steps": int(cfg.n_steps), "batch_size": int(cfg.batch_size), "n_epochs": int(cfg.n_epochs),
         "gamma": float(cfg.gamma), "gae_lambda": float(cfg.gae_lambda), "ent_coef": float(cfg.ent_coef), "vf_coef": float(cfg.vf_coef),
         "max_grad_norm": float(cfg.max_grad_norm), "normalize_advantage": bool(cfg.normalize_advantage),
@@ -74,10 +79,12 @@ def _policy_data(ppo, env_cfg: kcfg.EnvConfig | None) -> dict[str, Any]:
         "_last_obs": None, "_last_episode_starts": None, "_last_original_obs": None, "_episode_num": 0, "_current_progress_remaining": 1.0,
         "_stats_window_size": 100, "ep_info_buffer": None, "ep_success_buffer": None,
         "rollout_buffer_class": {":type:": "<class 'abc.ABCMeta'>", "__module__": "stable_baselines3.common.buffers", "__name__": "DictRolloutBuffer",
-                                 ":serialized:": None},
+                                 ":serialized:": sbp.serialized(sbp.ROLLOUT_BUFFER_CLASS)},
         "rollout_buffer_kwargs": {},
         "kp1_engine": {"writer": "rl_brain_trainer_amd.checkpoint", "sb3_loadable": False,
-                       "needs": "tools/finish_sb3_zip.py on a host with stable-baselines3==" + SB3_VERSION_PIN,
+                       "needs": "the pickled members are assembled without gymnasium / SB3 (rl_brain_trainer_amd/sb3_pickle.py) and have never been read by "
+                                "the real PPO.load: until one has, treat tools/finish_sb3_zip.py on a host with stable-baselines3==" + SB3_VERSION_PIN +
+                                " as the route that is correct by construction",
                        "adam_steps": int(ppo.adam_t), "mode": env_cfg.mode_name if env_cfg else None},
     }
 

@@ -114,7 +114,18 @@ def test_checkpoint_data_member_has_every_sb3_key():
     json.loads(json.dumps(data))                                   # JSON-typed all the way down
     assert data["_n_updates"] == 8 and data["kp1_engine"]["adam_steps"] == 384     # SB3 counts n_epochs per train() call, not Adam steps
     assert data["policy_kwargs"] == {} and data["kp1_engine"]["sb3_loadable"] is False
-    assert all(data[k][":serialized:"] is None for k in ck.PICKLED_MEMBERS)
+    # the six pickled members: payloads assembled without gymnasium / SB3; read back here from the OPCODE stream only (nothing is unpickled:
+    # the classes they name are not importable in this image) -- the GLOBALs must be exactly the classes SB3's loader expects
+    from rl_brain_trainer_amd import sb3_pickle as sbp
+
+    refs = {k: sbp.describe(data[k][":serialized:"]) for k in ck.PICKLED_MEMBERS}
+    assert refs["policy_class"] == [("stable_baselines3.common.policies", "MultiInputActorCriticPolicy")]
+    assert refs["rollout_buffer_class"] == [("stable_baselines3.common.buffers", "DictRolloutBuffer")]
+    for k in ("lr_schedule", "clip_range"):
+        assert set(refs[k]) == {("stable_baselines3.common.utils", "FloatSchedule"), ("stable_baselines3.common.utils", "ConstantSchedule")}
+    assert ("gymnasium.spaces.dict", "Dict") in refs["observation_space"] and ("gymnasium.spaces.box", "Box") in refs["observation_space"]
+    assert ("gymnasium.spaces.box", "Box") in refs["action_space"]
+    assert all(m.split(".")[0] in ("gymnasium", "stable_baselines3", "numpy", "copy_reg", "copyreg", "_codecs") for v in refs.values() for m, _ in v)
     fake.cfg = PPOConfig(hidden=256)
     assert ck._policy_data(fake, None)["policy_kwargs"] == {"net_arch": {"pi": [256, 256], "vf": [256, 256]}}
 
@@ -139,3 +150,39 @@ def test_finisher_yaml_resolves_to_reference_config():
     ours = kcfg.to_env_config(raw, handoff_base_dirs=(GOLDEN,))
     gold = load_golden_config("dock_workspace_handoff_noop_ft_12env_raw")
     assert bytes(ours.c) == bytes(gold.c)
+
+
+def test_sb3_pickle_payloads_rebuild_the_documented_state(monkeypatch):
+    """The payloads of rl_brain_trainer_amd/sb3_pickle.py are well-formed pickle streams that rebuild, under modules of the real names, objects
+    with the attribute state the module documents.  The modules here are EMPTY stand-ins created by this test (gymnasium / SB3 are not
+    importable in this image: what the real classes do with that state is the unpinned part); the streams are this build's own output."""
+    import base64
+    import pickle
+    import sys
+    import types
+
+    import numpy as np
+
+    from rl_brain_trainer_amd import sb3_pickle as sbp
+
+    for module, names in (("gymnasium.spaces.box", ("Box",)), ("gymnasium.spaces.dict", ("Dict",)),
+                          ("stable_baselines3.common.utils", ("FloatSchedule", "ConstantSchedule")),
+                          ("stable_baselines3.common.policies", ("MultiInputActorCriticPolicy",)), ("stable_baselines3.common.buffers", ("DictRolloutBuffer",))):
+        parts = module.split(".")
+        for k in range(1, len(parts) + 1):
+            name = ".".join(parts[:k])
+            if name not in sys.modules:
+                monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+        for cls in names:
+            setattr(sys.modules[module], cls, type(cls, (), {"__module__": module}))
+    load = lambda payload: pickle.loads(base64.b64decode(payload))   # noqa: E731
+    space = load(sbp.serialized(sbp.dict_space({"b_key": sbp.box(-1.0, 1.0, 7), "a_key": sbp.box(0.0, 1.0, 2)})))
+    assert type(space).__name__ == "Dict" and list(space.spaces) == ["a_key", "b_key"] and space._shape is None and space._np_random is None
+    b = space.spaces["b_key"]
+    assert type(b).__module__ == "gymnasium.spaces.box" and b._shape == (7,) and b.dtype == np.float32
+    assert b.low.dtype == np.float32 and np.array_equal(b.low, -np.ones(7, np.float32)) and np.array_equal(b.high, np.ones(7, np.float32))
+    assert b.bounded_below.all() and b.bounded_above.all() and b.low_repr == "-1.0" and space.spaces["a_key"].low_repr == "0.0"
+    sched = load(sbp.serialized(sbp.float_schedule(3e-4)))
+    assert type(sched).__name__ == "FloatSchedule" and type(sched.value_schedule).__name__ == "ConstantSchedule" and sched.value_schedule.val == 3e-4
+    assert load(sbp.serialized(sbp.POLICY_CLASS)) is sys.modules["stable_baselines3.common.policies"].MultiInputActorCriticPolicy
+    assert load(sbp.serialized(sbp.ROLLOUT_BUFFER_CLASS)) is sys.modules["stable_baselines3.common.buffers"].DictRolloutBuffer

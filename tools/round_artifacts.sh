@@ -21,5 +21,7 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_env/$t -o pmc -- python3 tools/env_kernel_bench.py --launches 100 > $out/pmc_env.$t.log 2>&1 || { echo "env pmc pass $c FAILED"; exit 1; }
   echo "pmc pass $c ok"
 done
+bash tools/sq_passes.sh $tag/sq > $out/sq.log 2>&1 && python3 tools/sq_summary.py $out/sq profiles/$tag > $out/sq_summary.log 2>&1 && cp profiles/${tag}_sq_counters.* $out/ && rm -rf $out/sq && echo "sq counters ok" || { echo "sq passes FAILED"; tail -5 $out/sq.log; }
 python tools/pmc_summary.py $out/pmc profiles/$tag > $out/pmc_summary.log 2>&1 && python tools/pmc_summary.py $out/pmc_env profiles/$tag @32768 >> $out/pmc_summary.log 2>&1 && cp profiles/${tag}_pmc_* $out/ && echo "pmc summary ok"
+rm -rf $out/stats $out/cfg3 $out/pmc $out/pmc_env   # raw rocprof outputs: only the summaries travel back (gpurun_out/ is capped at 64 MiB)
 timeout -k 10 500 python bench.py > $out/bench.json 2> $out/bench.err && echo "bench ok" && python3 tools/bench_line.py $out/bench.json
