@@ -206,6 +206,11 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
  * step left them) rather than in a back-to-back micro loop.  kp1_mlp_profile_read waits for the recorded launches and returns, per
  * slot, the average duration in microseconds and the launch count since the last read.  Not usable while a hipGraph is being captured. */
 #define KP1_MLP_OPT_PROFILE 4
+/* KP1_MLP_OPT_BF16X3_WGRAD (default 0) -- EXPERIMENT, not the measured product path: the weight-gradient GEMMs dW2 = dZ2^T h1, dW1 = dZ1^T X on
+ * operands the tile kernel pre-splits into three bf16 pieces (x = hi + mid + lo, 24 bits) and six bf16 MFMAs per product block, fp32 accumulation
+ * (gemm_tn_bf16x3_kernel) instead of the exact fp32 MFMA kernel.  Not bit-identical to the exact path: error table in DESIGN.md / bench.py's
+ * `experiment_bf16x3_wgrad` block.  bench.py's `value` and `dtype` never use it. */
+#define KP1_MLP_OPT_BF16X3_WGRAD 5
 #define KP1_MLP_PROFILE_SLOTS 4
 #define KP1_MLP_PROFILE_TILE 0      /* mlp_tile_kernel<true, .>: forward + loss + activation backward of both nets */
 #define KP1_MLP_PROFILE_WGRAD 1     /* gemm_tn_frag_kernel: dW2 + dW1 of both nets */

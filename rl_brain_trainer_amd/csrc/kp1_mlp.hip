@@ -1166,6 +1166,9 @@ struct kp1_mlp {
   float* dz2 = nullptr;
   float* dz1 = nullptr;
   float* xf = nullptr;    // [max_batch][64] gathered observations, k8-fragment major (fused path)
+  // [r3 experiment, KP1_MLP_OPT_BF16X3_WGRAD] the same four tensors as three bf16 planes each, allocated when the option is first switched on
+  int bf16x3 = 0;
+  unsigned short* sp_h1 = nullptr; unsigned short* sp_dz2 = nullptr; unsigned short* sp_dz1 = nullptr; unsigned short* sp_xf = nullptr;
   double* partials = nullptr;  // [512]
   float* slab = nullptr;       // [64 chunks][2 nets][Hp][Hp] partial dW2
   float* slab1 = nullptr;      // [64 chunks][2 nets][Hp][64] partial dW1
@@ -1297,6 +1300,16 @@ int launch_fused(const FusedArgs& fa_in, hipStream_t stream) {
   fa.n_cus = n_cus;
   fa.stagger_ticks = (G::RB == 1 && (int)(grid.x * grid.z) > n_cus) ? stagger_us * 100 : 0;   // only when CUs hold two workgroups at once
   const size_t bytes = sizeof(float) * G::LDS_FLOATS;
+  if (fa.sp_h1 != nullptr) {   // [r3 experiment] bf16 x 3 planes instead of the fp32 activation copies
+    if (fa.inp == 64) {
+      HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<true, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      hipLaunchKernelGGL((mlp_tile_kernel<true, 2, 0, true>), grid, dim3(G::NTH), bytes, stream, fa);
+    } else {
+      HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<true, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      hipLaunchKernelGGL((mlp_tile_kernel<true, 4, 0, true>), grid, dim3(G::NTH), bytes, stream, fa);
+    }
+    return KP1_OK;
+  }
   if (fa.inp == 64) {
     HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     hipLaunchKernelGGL((mlp_tile_kernel<true, 2>), grid, dim3(G::NTH), bytes, stream, fa);
@@ -1476,6 +1489,7 @@ int kp1_mlp_destroy(kp1_mlp* m) {
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
   for (void* p : m->allocs) (void)hipFree(p);
+  for (void* p : {(void*)m->sp_h1, (void*)m->sp_dz2, (void*)m->sp_dz1, (void*)m->sp_xf}) (void)hipFree(p);
   for (auto& v : m->prof)
     for (auto& pr : v) {
       (void)hipEventDestroy(pr.a);
@@ -1499,6 +1513,21 @@ int kp1_mlp_set_option(kp1_mlp* m, int32_t option, int32_t value) {
       HIP_TRY(hipDeviceSynchronize());
       m->slab_stale = false;
     }
+    return KP1_OK;
+  }
+  if (option == KP1_MLP_OPT_BF16X3_WGRAD) {
+    if (value && !(m->fused && m->Hp == FU_HP)) return fail(KP1_ERR_UNSUPPORTED, "the bf16x3 weight-gradient experiment needs the 2x256 tile kernels");
+    if (value && !m->sp_h1) {
+      HIP_TRY(hipSetDevice(m->device));
+      const size_t act = (size_t)3 * 2 * m->max_batch * m->Hp * sizeof(unsigned short), xb = (size_t)3 * m->max_batch * m->L.INP * sizeof(unsigned short);
+      for (unsigned short** p : {&m->sp_h1, &m->sp_dz2, &m->sp_dz1}) {
+        HIP_TRY(hipMalloc((void**)p, act));
+        HIP_TRY(hipMemset(*p, 0, act));
+      }
+      HIP_TRY(hipMalloc((void**)&m->sp_xf, xb));
+      HIP_TRY(hipMemset(m->sp_xf, 0, xb));
+    }
+    m->bf16x3 = value ? 1 : 0;
     return KP1_OK;
   }
   if (option == KP1_MLP_OPT_PROFILE) {
@@ -1619,6 +1648,10 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
     fa.clip_range = clip_range; fa.vf_coef = vf_coef; fa.inv_count = inv_count;
     fa.h1 = m->h1; fa.dz2 = m->dz2; fa.dz1 = m->dz1; fa.act_stride = act_stride; fa.xf = m->xf;
     fa.bslab = m->bslab; fa.hpart = m->hpart; fa.hpart_stride = hpart_stride;
+    if (m->bf16x3) {
+      fa.sp_h1 = m->sp_h1; fa.sp_dz2 = m->sp_dz2; fa.sp_dz1 = m->sp_dz1; fa.sp_xf = m->sp_xf;
+      fa.sp_plane = (int64_t)2 * m->max_batch * Hp; fa.sp_plane_x = (int64_t)m->max_batch * INP;
+    }
     {
       ProfScope ps(m, KP1_MLP_PROFILE_TILE, stream);
       rc = launch_fused(fa, stream);
@@ -1674,7 +1707,17 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
     t.cg1 = up8((t.groups + KP1_TN_SPLIT1 - 1) / KP1_TN_SPLIT1);   // form 0: ~64 chunks x 4 tiles, form 1: 16 chunks x 16 tiles of quarter-size dW1 workgroups
     t.n_chunks2 = (t.groups + t.cg2 - 1) / t.cg2;
     t.n_chunks1 = (t.groups + t.cg1 - 1) / t.cg1;
-    {
+    if (m->bf16x3) {   // [r3 experiment] same slabs, same chunking in 16-row fragments
+      TnBf16Args b{};
+      b.dz2 = m->sp_dz2; b.h1 = m->sp_h1; b.dz1 = m->sp_dz1; b.plane = (int64_t)2 * m->max_batch * Hp; b.net = (int64_t)m->max_batch * Hp;
+      b.xf = m->sp_xf; b.plane_x = (int64_t)m->max_batch * INP; b.inp = INP;
+      b.slab2 = t.slab2; b.s2_net = t.s2_net; b.s2_chunk = t.s2_chunk; b.slab1 = t.slab1; b.s1_net = t.s1_net; b.s1_chunk = t.s1_chunk;
+      b.frags = t.groups / 2; b.cf2 = t.cg2 / 2; b.cf1 = t.cg1 / 2; b.n_chunks2 = t.n_chunks2; b.n_chunks1 = t.n_chunks1;   // groups, cg2, cg1 are multiples of 4 / 8
+      const size_t bytes = sizeof(float) * TN_SPLIT_LDS_FLOATS;
+      HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      ProfScope ps(m, KP1_MLP_PROFILE_WGRAD, stream);
+      hipLaunchKernelGGL(gemm_tn_bf16x3_kernel, dim3(32 * b.n_chunks2 + 16 * b.n_chunks1), dim3(256), bytes, stream, b);
+    } else {
       ProfScope ps(m, KP1_MLP_PROFILE_WGRAD, stream);
       rc = launch_tn_frag(t, stream);
     }

@@ -63,6 +63,13 @@ class MlpKernels:
         """Device-resident optimiser step count (restoring a checkpoint's Adam state)."""
         native.check(self.L.kp1_mlp_set_option(self._h, self.OPT_STEP_COUNT, int(steps)))
 
+    OPT_BF16X3_WGRAD = 5
+
+    def set_bf16x3_wgrad(self, on: bool) -> None:
+        """EXPERIMENT (default off): weight-gradient GEMMs on operands pre-split into three bf16 pieces, six bf16 MFMAs per product block
+        (gemm_tn_bf16x3_kernel).  Not the exact path; bench.py's value never uses it."""
+        native.check(self.L.kp1_mlp_set_option(self._h, self.OPT_BF16X3_WGRAD, int(bool(on))))
+
     OPT_PROFILE = 4
     PROFILE_SLOTS = ("mlp_train_tile", "gemm_tn_split", "grad_finalize", "adam")
 

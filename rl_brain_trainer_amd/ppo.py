@@ -401,6 +401,9 @@ class PPO:
             local_bs = max(cfg.batch_size // self.dist.world_size, 1)
             self._mlp = _mlp.MlpKernels(cfg.hidden, self.device, max_batch=max(N, local_bs, 8192), obs_dim=self.obs_dim)
             self._mlp.pack(self.policy.flat)
+            if os.environ.get("KP1_BF16X3_WGRAD", "0") == "1" and cfg.hidden == 256:
+                # round-3 EXPERIMENT (off by default, never used by bench.py's value): weight-gradient GEMMs on bf16 x 3 operands
+                self._mlp.set_bf16x3_wgrad(True)
             self.grad = torch.zeros_like(self.policy.flat)
             self.stats_dev = torch.zeros(4, dtype=torch.float32, device=dev)
             self.noise = torch.zeros((N, ACT_DIM), dtype=torch.float32, device=dev)

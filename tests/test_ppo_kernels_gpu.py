@@ -110,14 +110,18 @@ def test_mlp_forward_vs_torch(n, stride, fused):
     k.close()
 
 
-@pytest.mark.parametrize("fused", [True, False])
+# "bf16x3": the round-3 EXPERIMENT (KP1_MLP_OPT_BF16X3_WGRAD: weight-gradient GEMMs on operands split into three bf16 pieces) under the very same
+# tolerances as the exact fp32 kernels -- the acceptance condition the round-2 review set for it
+@pytest.mark.parametrize("fused", [True, False, "bf16x3"])
 @pytest.mark.parametrize("obs_dim", [56, 80])
 @pytest.mark.parametrize("n,total,gather", [(8192, 20000, True), (4096, 4096, False), (1000, 5000, True), (16384, 40000, True), (33, 64, True)])
 def test_mlp_loss_grad_vs_torch_autograd(n, total, gather, fused, obs_dim):
     D, W = obs_dim, (64 if obs_dim <= 64 else 128)
     pol = _policy(scale_heads=False, obs_dim=D)
     k = MlpKernels(256, DEV, max_batch=16384, obs_dim=D)
-    k.set_fused(fused)
+    k.set_fused(bool(fused))
+    if fused == "bf16x3":
+        k.set_bf16x3_wgrad(True)
     k.pack(pol.flat)
     g = torch.Generator(device=DEV).manual_seed(1)
     obs = torch.zeros((total, W), device=DEV)
