@@ -59,6 +59,23 @@ __device__ unsigned long long kp1_nt_trace_buf[KP1_TRACE_SLOTS * KP1_TRACE_WGS];
 #define KP1_TR_HW(slot)
 #endif
 
+// Developer check of the shader clock the matrix kernels actually run at (the guide's DVFS item 6: cycles of s_memtime per tick of the 100 MHz
+// s_memrealtime, stamped once at the start and once at the end of a workgroup; tools/mfma_clock.py builds with -DKP1_CLK_TRACE).  The stamps go to
+// a buffer nothing else reads.  Compiled out of the product.
+#ifdef KP1_CLK_TRACE
+__device__ unsigned long long kp1_clk_buf[2 * 1024 * 4];   // [kernel: 0 tile, 1 weight gradients][workgroup][cycles at start, ticks, cycles at end, ticks]
+#define KP1_CLK(kern, at)                                                                                     \
+  if (threadIdx.x == 0) {                                                                                     \
+    const int wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                           \
+    if (wg_ < 1024) {                                                                                         \
+      kp1_clk_buf[((kern) * 1024 + wg_) * 4 + 2 * (at)] = __builtin_readcyclecounter();                       \
+      kp1_clk_buf[((kern) * 1024 + wg_) * 4 + 2 * (at) + 1] = wall_clock64();                                 \
+    }                                                                                                         \
+  }
+#else
+#define KP1_CLK(kern, at)
+#endif
+
 // Cache policy of the big once-written / once-read streams (build switches; the defaults are the measured optimum).
 // aux bits of the gfx950 buffer instructions: 1 = sc0, 2 = nt, 16 = sc1.  sc1 stores are write-through: the line leaves the XCD's L2 when it
 // is written instead of at the kernel's end-of-launch write-back, and the consumer (another launch, mostly on another XCD) reads it from
@@ -1876,6 +1893,14 @@ int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32
   (void)hipEventDestroy(e1);
   return KP1_OK;
 }
+
+#ifdef KP1_CLK_TRACE
+int kp1_debug_clk_trace(unsigned long long* out) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(kp1_clk_buf), sizeof(unsigned long long) * 2 * 1024 * 4));
+  return KP1_OK;
+}
+#endif
 
 #ifdef KP1_NT_TRACE
 int kp1_debug_nt_trace(unsigned long long* out, int clear) {
