@@ -433,7 +433,13 @@ struct kp1_env {
 
 namespace {
 
-int block_for(int64_t n) { return n <= 65536 ? 64 : 256; }
+// One wave per workgroup at every size: the step kernel holds 500 vector registers, so a CU runs four waves (one per SIMD), and a 256-thread
+// workgroup can only be replaced when all four of its waves have finished.  64-thread workgroups let every SIMD take its next wave by itself:
+// 117.5 -> 99.1 us at 524 288 envs, 33.8 -> 31.3 us at 131 072 (profiles/r03_ab_env_block_size.log; KP1_BIG_BLOCK is the A/B switch).
+#ifndef KP1_BIG_BLOCK
+#define KP1_BIG_BLOCK 64
+#endif
+int block_for(int64_t n) { return n <= 65536 ? 64 : KP1_BIG_BLOCK; }
 
 
 template <typename R>

@@ -1,0 +1,1 @@
+for n in 131072 524288; do python tools/env_kernel_bench.py --envs $n --launches 200 | cut -c1-70; done
