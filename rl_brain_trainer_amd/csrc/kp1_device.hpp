@@ -297,6 +297,12 @@ __device__ __forceinline__ void kp_sincos_kin(double x, double* s, double* c) {
   *c = ((quad + 1) & 2) ? -b : b;
 }
 
+// the same chain as straight-line code specialised to the robot constants (tools/gen_fk_chain.py): what the fp32 handle runs
+#include "kp1_fk_generated.inc"
+#ifndef KP1_FK_GENERATED
+#define KP1_FK_GENERATED 1   // 0: the fp32 handle runs the generic chain on the constants of DevFk (A/B switch; the fp64 handle always does)
+#endif
+
 // Rotation and position of the chain.  FAST selects kp_sincos_kin (fp32 handle); the fp64 handle keeps the library sincos it is pinned with.
 template <typename R, bool FAST>
 __device__ __forceinline__ void fk_chain(const DevFk<R>& __restrict__ k, const R* __restrict__ q, R* __restrict__ p, R* __restrict__ Rm) {
@@ -354,7 +360,11 @@ __device__ __forceinline__ void fk_pose6_kin(const DevFk<double>& __restrict__ k
   } else {
 #pragma clang fp contract(off)
     double Rm[9], p[3];
+#if KP1_FK_GENERATED
+    fk_chain_generated(q, p, Rm);      // (k is not read: kp1_create has checked that the generated constants are fold_fk's, bit for bit)
+#else
     fk_chain<double, true>(k, q, p, Rm);
+#endif
     const float r0 = (float)Rm[0], r3 = (float)Rm[3], r6 = (float)Rm[6], r7 = (float)Rm[7], r8 = (float)Rm[8];
     pose[0] = (R)p[0];
     pose[1] = (R)p[1];

@@ -673,6 +673,13 @@ int kp1_create(const kp1_config* cfg, int32_t n_envs, int32_t device, int32_t re
   if (cfg->curriculum_enabled && cfg->n_stages == 0) return fail(KP1_ERR_INVALID, "curriculum enabled without stages");
   if (cfg->reward.n_orientation_milestones < 0 || cfg->reward.n_orientation_milestones > KP1_MAX_MILESTONES)
     return fail(KP1_ERR_INVALID, "n_orientation_milestones out of range");
+  {   // the fp32 handle's generated FK chain carries the robot constants as literals: they must be what fold_fk computes here, bit for bit
+    DevFk<double> fk;
+    fold_fk<double>(&fk);
+    static_assert(sizeof(DevFk<double>) == sizeof(FKG_CHECK), "FKG_CHECK lists DevFk<double> member by member");
+    if (std::memcmp(&fk, FKG_CHECK, sizeof fk) != 0)
+      return fail(KP1_ERR_UNSUPPORTED, "csrc/kp1_fk_generated.inc does not match the robot constants of kp1_env.hip: run python3 tools/gen_fk_chain.py and rebuild");
+  }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(KP1_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
   if (device < 0 || device >= count) return fail(KP1_ERR_INVALID, "device index out of range");

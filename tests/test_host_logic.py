@@ -186,3 +186,15 @@ def test_sb3_pickle_payloads_rebuild_the_documented_state(monkeypatch):
     assert type(sched).__name__ == "FloatSchedule" and type(sched.value_schedule).__name__ == "ConstantSchedule" and sched.value_schedule.val == 3e-4
     assert load(sbp.serialized(sbp.POLICY_CLASS)) is sys.modules["stable_baselines3.common.policies"].MultiInputActorCriticPolicy
     assert load(sbp.serialized(sbp.ROLLOUT_BUFFER_CLASS)) is sys.modules["stable_baselines3.common.buffers"].DictRolloutBuffer
+
+
+def test_generated_fk_chain_is_current():
+    """csrc/kp1_fk_generated.inc (the fp32 handle's FK chain with the robot constants as literals) is what tools/gen_fk_chain.py produces from the
+    constants in kp1_env.hip today; kp1_create additionally compares the constants with fold_fk's at run time, bit for bit."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    out = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_fk_chain.py"), "--check"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
