@@ -88,8 +88,117 @@ __device__ __forceinline__ void tracker_store(kp1_curriculum_state* __restrict__
   }
 }
 
+// [r3] Many episodes in one block of 4096 envs (every env of a handle truncates in the same step when the episodes started together: 4096
+// finished episodes at once, which lane 0 replayed in ~600 us -- 1.4 % of the benchmark's iteration hidden in a "4.7 us" kernel).  Same result,
+// computed by the whole wave: the success bits in episode order go to LDS, a prefix count over (window contents ++ new bits) gives the window
+// sum after EVERY episode at once, the first episode that satisfies the promotion rule is a wave-min, and the ring / length / head / sum after
+// appending a run of episodes follow in closed form (entry j of a run lands in slot (head + len + j) mod window, full or not).  A promotion
+// empties the window and the search continues behind it.  Wave-uniform in, wave-uniform out; LDS scratch: 4096 bits-as-bytes + prefix counts.
+constexpr int TRK_BLOCK = 64 * 64, TRK_PARALLEL_MIN = 192;
+struct TrackerScratch { uint8_t* sbit; uint16_t* pfx; };
+
+// append episodes [pos, pos + R) of sbit to the window; no promotion check
+__device__ __forceinline__ void tracker_append_run(int* __restrict__ ring, TrackerCtx& c, const uint8_t* __restrict__ sbit, int pos, int R) {
+  const int lane = threadIdx.x, W = c.window;
+  const int j0 = R > W ? R - W : 0;                       // earlier entries of the run are overwritten by later ones
+  __syncthreads();
+  for (int j = j0 + lane; j < R; j += 64) ring[(c.head + c.len + j) % W] = sbit[pos + j];
+  __syncthreads();
+  const int over = c.len + R - W;
+  c.head = over > 0 ? (c.head + over) % W : c.head;
+  c.len = c.len + R < W ? c.len + R : W;
+  c.count += R;
+  int part = 0;
+  for (int k = lane; k < W; k += 64) {
+    const int age = k >= c.head ? k - c.head : k - c.head + W;
+    if (age < c.len) part += ring[k];
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  c.sum = part;
+}
+
+__device__ __forceinline__ void tracker_block_parallel(kp1_curriculum_state* __restrict__ st, int* __restrict__ ring, TrackerCtx& c, const TrackerScratch& ws,
+                                                       unsigned long long dmask, unsigned long long smask, int E) {
+  const int lane = threadIdx.x, W = c.window;
+  // success bits in episode (= env) order
+  int mine = __popcll(dmask), off = mine;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(off, d);
+    if (lane >= d) off += up;
+  }
+  off -= mine;                                            // exclusive prefix: index of this lane's first finished episode
+  __syncthreads();
+  for (unsigned long long m = dmask; m; m &= m - 1) {
+    const int b = __ffsll((long long)m) - 1;
+    ws.sbit[off++] = (uint8_t)((smask >> b) & 1ull);
+  }
+  __syncthreads();
+  int pos = 0;
+  while (pos < E) {
+    const int R = E - pos;
+    if (c.stage >= c.max_stage) {                          // last stage: the window only records
+      tracker_append_run(ring, c, ws.sbit, pos, R);
+      break;
+    }
+    // prefix counts Q[0 .. L + R] over Y = (window contents, oldest first) ++ sbit[pos ..): Q[j] = successes among the first j entries of Y
+    const int L = c.len, T = L + R;
+    const int seg = (T + 63) / 64, j_lo = lane * seg < T ? lane * seg : T, j_hi = j_lo + seg < T ? j_lo + seg : T;
+    auto y = [&](int j) -> int { return j < L ? ring[(c.head + j) % W] : (int)ws.sbit[pos + (j - L)]; };
+    int tot = 0;
+    for (int j = j_lo; j < j_hi; ++j) tot += y(j);
+    int run = tot;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(run, d);
+      if (lane >= d) run += up;
+    }
+    run -= tot;
+    __syncthreads();
+    if (lane == 0) ws.pfx[0] = 0;
+    for (int j = j_lo; j < j_hi; ++j) {
+      run += y(j);
+      ws.pfx[j + 1] = (uint16_t)run;
+    }
+    __syncthreads();
+    // first episode r of the run after whose append the rule holds: count + r + 1 >= min_episodes, window full, rate >= threshold
+    int best = R;
+    for (int r = lane; r < R; r += 64) {
+      const int filled = L + r + 1;
+      if (filled < W || c.count + r + 1 < c.min_episodes) continue;
+      const int wsum = (int)ws.pfx[filled] - (int)ws.pfx[filled - W];
+      if ((double)wsum / (double)W >= c.threshold) {
+        best = r;
+        break;                                            // r only grows along this lane's stride
+      }
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+      const int o = __shfl_xor(best, d);
+      best = o < best ? o : best;
+    }
+    if (best >= R) {                                       // no promotion inside this run
+      tracker_append_run(ring, c, ws.sbit, pos, R);
+      break;
+    }
+    const int filled = L + best + 1;
+    const double rate = (double)((int)ws.pfx[filled] - (int)ws.pfx[filled - W]) / (double)W;
+    if (lane == 0 && c.n_events < KP1_CURRICULUM_MAX_HISTORY) {
+      kp1_curriculum_event& ev = st->events[c.n_events];
+      ev.total_timesteps = c.timesteps;
+      ev.from_stage = c.stage;
+      ev.to_stage = c.stage + 1;
+      ev.trigger_success_rate = rate;
+    }
+    c.n_events += 1;
+    c.stage += 1;
+    c.count = 0;
+    c.len = 0;
+    c.head = 0;
+    c.sum = 0;
+    pos += best + 1;
+  }
+}
+
 // consume dones[0 .. n) in index order.  c is wave-uniform on entry and on exit (lane 0's values are broadcast at the end).
-__device__ __forceinline__ void curriculum_scan(kp1_curriculum_state* __restrict__ st, int* __restrict__ ring, TrackerCtx& c,
+__device__ __forceinline__ void curriculum_scan(kp1_curriculum_state* __restrict__ st, int* __restrict__ ring, TrackerCtx& c, const TrackerScratch& ws,
                                                 const uint8_t* __restrict__ dones, int n, int steps_per_call) {
   const int lane = threadIdx.x;
   c.timesteps += steps_per_call;
@@ -128,6 +237,14 @@ __device__ __forceinline__ void curriculum_scan(kp1_curriculum_state* __restrict
     unsigned long long busy = __ballot(dmask != 0ull);
     if (busy == 0ull) continue;
     c.ring_dirty = true;
+    {
+      int ended = __popcll(dmask);
+      for (int off = 32; off > 0; off >>= 1) ended += __shfl_xor(ended, off);
+      if (ended >= TRK_PARALLEL_MIN) {                     // wave-uniform
+        tracker_block_parallel(st, ring, c, ws, dmask, smask, ended);
+        continue;
+      }
+    }
     int stage = c.stage, count = c.count, len = c.len, head = c.head, sum = c.sum, n_events = c.n_events;
     const int window = c.window;
     while (busy) {   // lanes that saw a finished episode, in lane (= env) order
@@ -179,9 +296,12 @@ __device__ __forceinline__ void curriculum_scan(kp1_curriculum_state* __restrict
 __global__ void __launch_bounds__(64) curriculum_kernel(kp1_curriculum_state* __restrict__ st, const uint8_t* __restrict__ dones, int n,
                                                         int steps_per_call) {
   __shared__ int ring[KP1_CURRICULUM_MAX_WINDOW];
+  __shared__ uint8_t sbit[TRK_BLOCK];
+  __shared__ uint16_t pfx[TRK_BLOCK + KP1_CURRICULUM_MAX_WINDOW + 1];
+  const TrackerScratch ws = {sbit, pfx};
   TrackerCtx c;
   tracker_load(st, ring, c);
-  curriculum_scan(st, ring, c, dones, n, steps_per_call);
+  curriculum_scan(st, ring, c, ws, dones, n, steps_per_call);
   tracker_store(st, ring, c);
 }
 
@@ -192,11 +312,14 @@ __global__ void __launch_bounds__(64) curriculum_kernel(kp1_curriculum_state* __
 __global__ void __launch_bounds__(64) curriculum_chunk_kernel(kp1_curriculum_state* __restrict__ st, const uint8_t* __restrict__ dones, int n_local,
                                                               int chunk_steps, int world, int steps_per_env_step) {
   __shared__ int ring[KP1_CURRICULUM_MAX_WINDOW];
+  __shared__ uint8_t sbit[TRK_BLOCK];
+  __shared__ uint16_t pfx[TRK_BLOCK + KP1_CURRICULUM_MAX_WINDOW + 1];
+  const TrackerScratch ws = {sbit, pfx};
   TrackerCtx c;
   tracker_load(st, ring, c);
   for (int t = 0; t < chunk_steps; ++t)
     for (int r = 0; r < world; ++r)
-      curriculum_scan(st, ring, c, dones + ((int64_t)r * chunk_steps + t) * n_local, n_local, r == 0 ? steps_per_env_step : 0);
+      curriculum_scan(st, ring, c, ws, dones + ((int64_t)r * chunk_steps + t) * n_local, n_local, r == 0 ? steps_per_env_step : 0);
   tracker_store(st, ring, c);
 }
 

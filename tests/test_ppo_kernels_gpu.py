@@ -259,6 +259,45 @@ def test_device_curriculum_matches_golden_tracker():
         cur.close()
 
 
+@pytest.mark.parametrize("window,min_eps,max_stage,n_big", [(64, 100, 11, 4096), (20, 48, 5, 8192), (48, 300, 2, 5000), (1000, 1100, 3, 4096)])
+def test_device_curriculum_parallel_path_equals_serial_replay(window, min_eps, max_stage, n_big):
+    """The tracker's whole-wave path (>= 192 finished episodes in a block of 4096 envs: prefix counts, first promotion by wave-min, closed-form
+    window update) against its serial lane-0 replay, which the golden traces pin: the same episode stream fed as big VecEnv steps (every env
+    finishes: 4096 / 8192 / 5000 with idle envs) and as 64-env steps must leave the same stage, episode count, window (length, head, live
+    entries) and promotion history (from / to / trigger rate).  Success rates drift up and down so that promotions fall inside, at the start and
+    at the end of blocks, several per block, and stop at the last stage."""
+    g = np.random.default_rng(window + n_big)
+    total = 60000
+    phase = np.sin(np.arange(total) / 1500.0) * 0.25 + 0.7
+    seq = (g.random(total) < phase).astype(np.uint8)
+    kw = dict(success_rate_threshold=0.75, window_episodes=window, min_episodes_per_stage=min_eps, max_stage_index=max_stage, initial_stage_index=0, device=0)
+    big, small = PointCurriculum(**kw), PointCurriculum(**kw)
+    used = 0
+    while used + n_big <= total:
+        dones = np.zeros(n_big, dtype=np.uint8)
+        k = n_big if n_big != 5000 else 4300                    # 5000 envs, 4300 of them finish (idle envs in between; second block ragged)
+        pos = np.arange(n_big) if k == n_big else np.sort(g.choice(n_big, size=k, replace=False))
+        dones[pos] = 2 | (seq[used:used + k] << 2)
+        big.observe(torch.tensor(dones, device=DEV), n_big)
+        for s0 in range(used, used + k, 64):
+            chunk = seq[s0:min(s0 + 64, used + k)]
+            d = np.zeros(64, dtype=np.uint8)
+            d[:len(chunk)] = 2 | (chunk << 2)
+            small.observe(torch.tensor(d, device=DEV), 64)
+        used += k
+        a, b = big.read(), small.read()
+        assert (a.stage_index, a.stage_episode_count, a.ring_len, a.ring_head, a.n_events) == (b.stage_index, b.stage_episode_count, b.ring_len, b.ring_head, b.n_events), used
+        live = [(a.ring_head + j) % window for j in range(a.ring_len)]
+        assert [a.ring[j] for j in live] == [b.ring[j] for j in live], used
+    a, b = big.read(), small.read()
+    assert a.n_events >= 1 and (a.stage_index == max_stage or a.n_events >= 2)
+    for k in range(min(a.n_events, 64)):
+        ea, eb = a.events[k], b.events[k]
+        assert (ea.from_stage, ea.to_stage, ea.trigger_success_rate) == (eb.from_stage, eb.to_stage, eb.trigger_success_rate), k
+    big.close()
+    small.close()
+
+
 def test_keyed_permutation_is_a_permutation_and_mixes():
     """kp1_random_permutation (the minibatch shuffle above 2^17 samples): a bijection of [0, n) for any n (cycle walking below the next
     power of two), different keys give different permutations, and consecutive outputs -- one minibatch is a run of them -- look like
