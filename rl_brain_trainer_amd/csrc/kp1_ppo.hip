@@ -94,7 +94,10 @@ __device__ __forceinline__ void tracker_store(kp1_curriculum_state* __restrict__
 // sum after EVERY episode at once, the first episode that satisfies the promotion rule is a wave-min, and the ring / length / head / sum after
 // appending a run of episodes follow in closed form (entry j of a run lands in slot (head + len + j) mod window, full or not).  A promotion
 // empties the window and the search continues behind it.  Wave-uniform in, wave-uniform out; LDS scratch: 4096 bits-as-bytes + prefix counts.
-constexpr int TRK_BLOCK = 64 * 64, TRK_PARALLEL_MIN = 192;
+#ifndef KP1_TRK_PARALLEL_MIN
+#define KP1_TRK_PARALLEL_MIN 192          // finished episodes per 4096-env block from which the whole-wave path is taken (A/B: 1 << 30 = never)
+#endif
+constexpr int TRK_BLOCK = 64 * 64, TRK_PARALLEL_MIN = KP1_TRK_PARALLEL_MIN;
 struct TrackerScratch { uint8_t* sbit; uint16_t* pfx; };
 
 // append episodes [pos, pos + R) of sbit to the window; no promotion check
