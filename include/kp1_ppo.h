@@ -201,8 +201,8 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
 /* KP1_MLP_OPT_STEP_COUNT: set the device-resident optimiser step count (PPO.load restores torch.optim.Adam's state, whose per-tensor
  * `step` feeds the bias corrections); kp1_mlp_loss_grad increments it, kp1_mlp_adam_step(step = 0) reads it. */
 #define KP1_MLP_OPT_STEP_COUNT 3
-/* KP1_MLP_OPT_PROFILE (default 0): record a HIP-event pair around every kernel launch of the optimiser step, on the launch stream and in
- * the real launch sequence, so that a kernel's average duration is measured in situ (caches in the state the previous kernel of the
+/* KP1_MLP_OPT_PROFILE (default 0): attach a HIP-event pair to every kernel launch of the optimiser step (the dispatch's own begin and end),
+ * on the launch stream and in the real launch sequence, so that a kernel's average duration is measured in situ (caches in the state the previous kernel of the
  * step left them) rather than in a back-to-back micro loop.  kp1_mlp_profile_read waits for the recorded launches and returns, per
  * slot, the average duration in microseconds and the launch count since the last read.  Not usable while a hipGraph is being captured. */
 #define KP1_MLP_OPT_PROFILE 4

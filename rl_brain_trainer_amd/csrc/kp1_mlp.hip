@@ -13,6 +13,7 @@
 // (row = (reg&3) + 8*(reg>>2) + 4*(l>>5), col = l&31).  K order inside a tile is free, so each lane reads 4 (NT) or
 // 1 (TN) consecutive k per LDS read and both operands use the same k for the same kslot.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdlib>
@@ -1201,9 +1202,9 @@ struct kp1_mlp {
   const float* last_params = nullptr;
   bool slab_stale = false;
   std::vector<void*> allocs;
-  // KP1_MLP_OPT_PROFILE: HIP-event pairs around every launch of the optimiser step, on the launch stream, in the real launch sequence
-  // (tile -> weight gradients -> finalize -> Adam), read back by kp1_mlp_profile_read.  Off in production (events cannot be recorded
-  // into a captured graph replay usefully, and they add a few us of host work per launch).
+  // KP1_MLP_OPT_PROFILE: a HIP-event pair attached to every launch of the optimiser step (hipExtLaunchKernelGGL: the dispatch's own begin
+  // and end), on the launch stream, in the real launch sequence (tile -> weight gradients -> finalize -> Adam), read back by
+  // kp1_mlp_profile_read.  Off in production (an eager epoch: events do not travel into a captured graph replay).
   int profile = 0;
   struct ProfPair { hipEvent_t a, b; };
   std::vector<ProfPair> prof[KP1_MLP_PROFILE_SLOTS];
@@ -1211,7 +1212,14 @@ struct kp1_mlp {
 };
 
 namespace {
-// records the a-event now and the b-event when it goes out of scope
+// The event pair of the profiled launch in flight on this thread.  KP1_LAUNCH hands it to hipExtLaunchKernelGGL, which attaches both events
+// to the kernel's own dispatch packet: their elapsed time is the dispatch's begin -> end, the interval rocprofv3 --kernel-trace reports.
+// (Round 2 recorded the events as separate stream markers around the launch; that interval also holds the marker -> dispatch hand-over,
+// 2-4 us on this stack, and read 50.6 us where rocprofv3 read 48.5 for the same launches.)  A scope whose launch site does not use
+// KP1_LAUNCH falls back to the marker pair.
+struct ProfSlotInFlight { hipEvent_t a = nullptr, b = nullptr; bool attached = false; };
+thread_local ProfSlotInFlight tl_prof;
+
 struct ProfScope {
   kp1_mlp* m; int slot; hipStream_t stream; bool on;
   ProfScope(kp1_mlp* m_, int slot_, hipStream_t s_) : m(m_), slot(slot_), stream(s_), on(m_->profile != 0) {
@@ -1222,14 +1230,31 @@ struct ProfScope {
       if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) { on = false; return; }
       v.push_back(p);
     }
-    (void)hipEventRecord(v[m->prof_used[slot]].a, stream);
+    tl_prof.a = v[m->prof_used[slot]].a;
+    tl_prof.b = v[m->prof_used[slot]].b;
+    tl_prof.attached = false;
   }
   ~ProfScope() {
     if (!on) return;
-    (void)hipEventRecord(m->prof[slot][m->prof_used[slot]].b, stream);
+    if (!tl_prof.attached) {   // nothing was launched through KP1_LAUNCH inside the scope: an empty marker pair (reads ~0)
+      (void)hipEventRecord(tl_prof.a, stream);
+      (void)hipEventRecord(tl_prof.b, stream);
+    }
+    tl_prof = ProfSlotInFlight{};
     m->prof_used[slot] += 1;
   }
 };
+
+// launch of a kernel that may be inside a ProfScope
+#define KP1_LAUNCH(kernel, grid, block, bytes, stream, ...)                                                        \
+  do {                                                                                                             \
+    if (tl_prof.a != nullptr && !tl_prof.attached) {                                                               \
+      tl_prof.attached = true;                                                                                     \
+      hipExtLaunchKernelGGL(kernel, grid, block, bytes, stream, tl_prof.a, tl_prof.b, 0, __VA_ARGS__);             \
+    } else {                                                                                                       \
+      hipLaunchKernelGGL(kernel, grid, block, bytes, stream, __VA_ARGS__);                                         \
+    }                                                                                                              \
+  } while (0)
 }  // namespace
 
 namespace {
@@ -1320,19 +1345,19 @@ int launch_fused(const FusedArgs& fa_in, hipStream_t stream) {
   if (fa.sp_h1 != nullptr) {   // [r3 experiment] bf16 x 3 planes instead of the fp32 activation copies
     if (fa.inp == 64) {
       HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<true, 2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-      hipLaunchKernelGGL((mlp_tile_kernel<true, 2, 0, true>), grid, dim3(G::NTH), bytes, stream, fa);
+      KP1_LAUNCH((mlp_tile_kernel<true, 2, 0, true>), grid, dim3(G::NTH), bytes, stream, fa);
     } else {
       HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<true, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-      hipLaunchKernelGGL((mlp_tile_kernel<true, 4, 0, true>), grid, dim3(G::NTH), bytes, stream, fa);
+      KP1_LAUNCH((mlp_tile_kernel<true, 4, 0, true>), grid, dim3(G::NTH), bytes, stream, fa);
     }
     return KP1_OK;
   }
   if (fa.inp == 64) {
     HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL((mlp_tile_kernel<true, 2>), grid, dim3(G::NTH), bytes, stream, fa);
+    KP1_LAUNCH((mlp_tile_kernel<true, 2>), grid, dim3(G::NTH), bytes, stream, fa);
   } else {
     HIP_TRY(hipFuncSetAttribute((const void*)mlp_tile_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL((mlp_tile_kernel<true, 4>), grid, dim3(G::NTH), bytes, stream, fa);
+    KP1_LAUNCH((mlp_tile_kernel<true, 4>), grid, dim3(G::NTH), bytes, stream, fa);
   }
   return KP1_OK;
 }
@@ -1378,7 +1403,7 @@ int launch_tn_frag(const TnFragArgs& t, hipStream_t stream) {
   {
     const size_t bytes = sizeof(float) * TN_SPLIT_LDS_FLOATS;
     HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL(gemm_tn_split_kernel, dim3(32 * t.n_chunks2 + 16 * t.n_chunks1), dim3(256), bytes, stream, t);
+    KP1_LAUNCH(gemm_tn_split_kernel, dim3(32 * t.n_chunks2 + 16 * t.n_chunks1), dim3(256), bytes, stream, t);
     return KP1_OK;
   }
 #endif
@@ -1733,7 +1758,7 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
       const size_t bytes = sizeof(float) * TN_SPLIT_LDS_FLOATS;
       HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
       ProfScope ps(m, KP1_MLP_PROFILE_WGRAD, stream);
-      hipLaunchKernelGGL(gemm_tn_bf16x3_kernel, dim3(32 * b.n_chunks2 + 16 * b.n_chunks1), dim3(256), bytes, stream, b);
+      KP1_LAUNCH(gemm_tn_bf16x3_kernel, dim3(32 * b.n_chunks2 + 16 * b.n_chunks1), dim3(256), bytes, stream, b);
     } else {
       ProfScope ps(m, KP1_MLP_PROFILE_WGRAD, stream);
       rc = launch_tn_frag(t, stream);
@@ -1773,7 +1798,7 @@ int kp1_mlp_loss_grad(kp1_mlp* m, const float* obs, int32_t obs_stride, const in
   if (m->n_finalize_blocks > 2048) return fail(KP1_ERR_INVALID, "parameter vector too large for the sum-of-squares partial buffer");
   {
     ProfScope ps(m, KP1_MLP_PROFILE_FINALIZE, stream);
-    hipLaunchKernelGGL(grad_finalize_kernel, dim3(m->n_finalize_blocks), dim3(256), 0, stream, f, n_main);
+    KP1_LAUNCH(grad_finalize_kernel, dim3(m->n_finalize_blocks), dim3(256), 0, stream, f, n_main);
   }
   HIP_TRY(kp1::launch_status());
   return KP1_OK;
@@ -1942,10 +1967,10 @@ int kp1_mlp_adam_step(kp1_mlp* m, float* params, float* grad, float* exp_avg, fl
                                           reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;
   const int* step_arg = step > 0 ? (const int*)nullptr : (const int*)m->step_dev;
   if (vec4)
-    hipLaunchKernelGGL(adam_kernel<4>, dim3((unsigned)((n + 4 * KP1_ADAM_BLOCK - 1) / (4 * KP1_ADAM_BLOCK))), dim3(KP1_ADAM_BLOCK), 0, stream, params, grad, exp_avg, exp_avg_sq, n, norm_partials,
+    KP1_LAUNCH(adam_kernel<4>, dim3((unsigned)((n + 4 * KP1_ADAM_BLOCK - 1) / (4 * KP1_ADAM_BLOCK))), dim3(KP1_ADAM_BLOCK), 0, stream, params, grad, exp_avg, exp_avg_sq, n, norm_partials,
                        n_norm_partials, lr, eps, max_grad_norm, bc1, std::sqrt(bc2), m->L, kfmt, zero_grad, step_arg, host_step, (const int*)m->step_dev + 1);
   else
-    hipLaunchKernelGGL(adam_kernel<1>, dim3((unsigned)((n + KP1_ADAM_BLOCK - 1) / KP1_ADAM_BLOCK)), dim3(KP1_ADAM_BLOCK), 0, stream, params, grad, exp_avg, exp_avg_sq, n, norm_partials,
+    KP1_LAUNCH(adam_kernel<1>, dim3((unsigned)((n + KP1_ADAM_BLOCK - 1) / KP1_ADAM_BLOCK)), dim3(KP1_ADAM_BLOCK), 0, stream, params, grad, exp_avg, exp_avg_sq, n, norm_partials,
                        n_norm_partials, lr, eps, max_grad_norm, bc1, std::sqrt(bc2), m->L, kfmt, zero_grad, step_arg, host_step, (const int*)m->step_dev + 1);
   HIP_TRY(kp1::launch_status());
   return KP1_OK;
