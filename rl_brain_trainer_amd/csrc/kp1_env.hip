@@ -32,9 +32,19 @@ namespace {
 
 template <typename R, int MODE, bool COMPS>
 __global__ void __launch_bounds__(256, KP1_STEP_MIN_WAVES) kp1_step_kernel(const StepArgs<R> a) {
+  extern __shared__ float obs_tiles[];   // OBS_TILE_FLOATS per wave of the workgroup
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.st.n) return;
-  step_env_lane<R, MODE, COMPS>(a, i, a.actions + i * NJ);
+  const bool live = i < a.st.n;
+  float o[KP1_OBS_DIM];
+  if (live) step_env_lane<R, MODE, COMPS>(a, i, a.actions + i * NJ, o);
+  const int64_t i0 = i - (int64_t)(threadIdx.x & 63u);
+  const int64_t left = a.st.n - i0;
+  store_obs_tile(a.obs, i0, left >= 64 ? 64 : (left > 0 ? (int)left : 0), o, live, a.obs_stride, obs_tiles + (threadIdx.x >> 6) * OBS_TILE_FLOATS);
+  KP1_ETR(8)
+#ifdef KP1_ENV_TRACE
+  __builtin_amdgcn_s_waitcnt(0);   // every store of this wave acknowledged
+  KP1_ETR(9)
+#endif
 }
 
 template <typename R, int MODE>
@@ -516,12 +526,13 @@ int launch_step(kp1_env* e, const void* actions, float* obs, void* reward, uint8
   const int block = block_for(e->n);
   const dim3 grid((unsigned)((e->n + block - 1) / block));
   const bool comps = e->comps_enabled && e->comps;
+  const size_t lds = sizeof(float) * OBS_TILE_FLOATS * (size_t)(block / 64);   // one observation tile per wave (store_obs_tile)
   if (e->mode == KP1_MODE_DOCK) {
-    if (comps) hipLaunchKernelGGL((kp1_step_kernel<R, KP1_MODE_DOCK, true>), grid, dim3(block), 0, e->stream, a);
-    else hipLaunchKernelGGL((kp1_step_kernel<R, KP1_MODE_DOCK, false>), grid, dim3(block), 0, e->stream, a);
+    if (comps) hipLaunchKernelGGL((kp1_step_kernel<R, KP1_MODE_DOCK, true>), grid, dim3(block), lds, e->stream, a);
+    else hipLaunchKernelGGL((kp1_step_kernel<R, KP1_MODE_DOCK, false>), grid, dim3(block), lds, e->stream, a);
   } else {
-    if (comps) hipLaunchKernelGGL((kp1_step_kernel<R, KP1_MODE_APPROACH, true>), grid, dim3(block), 0, e->stream, a);
-    else hipLaunchKernelGGL((kp1_step_kernel<R, KP1_MODE_APPROACH, false>), grid, dim3(block), 0, e->stream, a);
+    if (comps) hipLaunchKernelGGL((kp1_step_kernel<R, KP1_MODE_APPROACH, true>), grid, dim3(block), lds, e->stream, a);
+    else hipLaunchKernelGGL((kp1_step_kernel<R, KP1_MODE_APPROACH, false>), grid, dim3(block), lds, e->stream, a);
   }
   HIP_TRY(kp1::launch_status());
   return KP1_OK;
