@@ -60,4 +60,7 @@ print(f"wave start spread: {np.percentile(t[:, 0] - first, [0, 50, 100])} cycles
 for k, nm in enumerate(names):
     d = t[:, k + 1] - t[:, k]
     print(f"  {nm:46s} median {np.median(d):8.0f}  min {d.min():8d}  max {d.max():8d} cycles")
+if (t[:, 10] > 0).all():   # slot 10 = end of step_env_lane (reward / done / state stores issued), before the observation tile store
+    a_, b_ = t[:, 10] - t[:, 7], t[:, 8] - t[:, 10]
+    print(f"  of the store phase: reward/done/state stores {np.median(a_):6.0f}, observation tile (LDS transpose + 16 stores) {np.median(b_):6.0f} cycles")
 env.close()
