@@ -302,6 +302,34 @@ __global__ void __launch_bounds__(64) curriculum_kernel(kp1_curriculum_state* __
   __shared__ uint8_t sbit[TRK_BLOCK];
   __shared__ uint16_t pfx[TRK_BLOCK + KP1_CURRICULUM_MAX_WINDOW + 1];
   const TrackerScratch ws = {sbit, pfx};
+  // [r3] the common VecEnv step ends no episode: then the only state that changes is num_timesteps, and the kernel is ONE round of loads (the
+  // done bytes) + a fire-and-forget add instead of three dependent round trips (state -> window -> done bytes) + the state stores
+#ifndef KP1_TRK_FAST_EMPTY
+#define KP1_TRK_FAST_EMPTY 1
+#endif
+  if (KP1_TRK_FAST_EMPTY) {
+    const int lane = threadIdx.x;
+    bool any = false;
+    for (int base = 0; base < n; base += 64 * 64) {
+      const int first = base + lane * 64;
+      if (first + 64 <= n && (reinterpret_cast<uintptr_t>(dones + first) & 15) == 0) {
+        const uint4* p = reinterpret_cast<const uint4*>(dones + first);
+        unsigned int acc = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint4 w = p[q];
+          acc |= w.x | w.y | w.z | w.w;
+        }
+        any |= (acc & (0x01010101u * (unsigned)(KP1_DONE_TERMINATED | KP1_DONE_TRUNCATED))) != 0u;
+      } else {
+        for (int b = 0; b < 64 && first + b < n; ++b) any |= (dones[first + b] & (KP1_DONE_TERMINATED | KP1_DONE_TRUNCATED)) != 0;
+      }
+    }
+    if (__ballot(any) == 0ull) {
+      if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&st->num_timesteps), (unsigned long long)(long long)steps_per_call);
+      return;
+    }
+  }
   TrackerCtx c;
   tracker_load(st, ring, c);
   curriculum_scan(st, ring, c, ws, dones, n, steps_per_call);
