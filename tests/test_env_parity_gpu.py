@@ -357,6 +357,37 @@ def test_full_size_properties_config3():
     small.close()
 
 
+@pytest.mark.parametrize("stride", [56, 64])
+@pytest.mark.parametrize("n", [1, 37, 64, 100, 129, 4096 + 5])
+def test_step_observation_block_store_ragged_sizes(n, stride):
+    """kp1_step writes a wave's observation rows as one transposed block (store_obs_tile: whole-line stores through LDS); kp1_observe rebuilds the
+    same rows from the stored state and writes them row by row.  Both must hold the same bits for every env count (full waves, a ragged last wave,
+    fewer envs than a wave) and both row pitches, over steps with and without auto-resets; the zero columns of a 64-float row stay zero and nothing
+    is written past the last env's row."""
+    cfg = load_golden_config("workspace_expansion_bigtrain")
+    env = ArmKinematicVecEnv(cfg, n, seed=11, real="f32")
+    env.set_curriculum_stage(5)
+    if stride != 56:
+        env.set_obs_stride(stride)
+    env.reset()
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    guard = torch.full((n + 2, stride), 7.0, dtype=torch.float32, device="cuda")     # one guard row on either side of the output block
+    rew = torch.zeros(n, device="cuda")
+    done = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    saw_reset = False
+    for t in range(98):
+        a = (torch.rand((n, 7), device="cuda", generator=gen) * 2 - 1).contiguous()
+        env.step_into(a, guard[1:n + 1], rew, done, None, True)
+        ref = env.current_observation()
+        assert torch.equal(guard[1:n + 1], ref), (t, n, stride)
+        assert torch.all(guard[0] == 7.0) and torch.all(guard[n + 1] == 7.0)
+        if stride == 64:
+            assert torch.all(guard[1:n + 1, 56:] == 0)
+        saw_reset |= bool((done & 3).any())
+    assert saw_reset
+    env.close()
+
+
 def test_error_behaviour():
     cfg = load_golden_config("approach_default")
     env = ArmKinematicVecEnv(cfg, 8, seed=1)
