@@ -34,6 +34,9 @@ template <typename R, int MODE, bool COMPS>
 __global__ void __launch_bounds__(256, KP1_STEP_MIN_WAVES) kp1_step_kernel(const StepArgs<R> a) {
   extern __shared__ float obs_tiles[];   // OBS_TILE_FLOATS per wave of the workgroup
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#ifdef KP1_ENV_TRACE   // slots 11 / 12: the chip-wide 100 MHz clock at wave entry / exit (the shader clock of slots 0..10 is not comparable across the chip)
+  if ((threadIdx.x & 63) == 0 && (i >> 6) < KP1_ENV_TRACE_WAVES) kp1_env_trace_buf[(i >> 6) * KP1_ENV_TRACE_SLOTS + 11] = __builtin_amdgcn_s_memrealtime();
+#endif
   const bool live = i < a.st.n;
   float o[KP1_OBS_DIM];
   if (live) step_env_lane<R, MODE, COMPS>(a, i, a.actions + i * NJ, o);
@@ -44,6 +47,7 @@ __global__ void __launch_bounds__(256, KP1_STEP_MIN_WAVES) kp1_step_kernel(const
 #ifdef KP1_ENV_TRACE
   __builtin_amdgcn_s_waitcnt(0);   // every store of this wave acknowledged
   KP1_ETR(9)
+  if ((threadIdx.x & 63) == 0 && (i >> 6) < KP1_ENV_TRACE_WAVES) kp1_env_trace_buf[(i >> 6) * KP1_ENV_TRACE_SLOTS + 12] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 

@@ -55,8 +55,11 @@ t = t[t[:, 0] > 0]
 names = ["entry -> cfg warm-up issued+landed", "state loads -> prev pose error", "action / q integration", "FK (fp64 chain) + Euler", "pose error, counters, termination",
          "reward", "observation build", "reward/done/state/obs stores issued", "stores acknowledged"]
 print(f"{n} envs, stage {stage}: {t.shape[0]} waves traced; host-timed launch {st.elapsed_time(en) * 1e3:.1f} us")
-first = t[:, 0].min()
-print(f"wave start spread: {np.percentile(t[:, 0] - first, [0, 50, 100])} cycles; wave lifetime median {np.median(t[:, 9] - t[:, 0]):.0f} cycles")
+# slots 11 / 12: the chip-wide 100 MHz clock at wave entry / exit (10 ns ticks); the shader clock of the phase stamps is per XCD
+t0r, t1r = t[:, 11], t[:, 12]
+print(f"chip clock: first wave start -> last wave START {(t0r.max() - t0r.min()) * 0.01:.2f} us, -> last wave END {(t1r.max() - t0r.min()) * 0.01:.2f} us; "
+      f"wave lifetime median {np.median(t1r - t0r) * 0.01:.2f} us ({np.median(t[:, 9] - t[:, 0]):.0f} shader cycles); start-time deciles (us) "
+      f"{np.round(np.percentile(t0r - t0r.min(), [10, 30, 50, 70, 90]) * 0.01, 2)}")
 for k, nm in enumerate(names):
     d = t[:, k + 1] - t[:, k]
     print(f"  {nm:46s} median {np.median(d):8.0f}  min {d.min():8d}  max {d.max():8d} cycles")
