@@ -220,7 +220,10 @@ class Dist:
         import torch.distributed as dist
 
         self.dist = dist
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # KP1_DIST_FORCE_SINGLE=1 (test hook): a one-rank process group takes the data-parallel code path too, so that the RCCL calls, their
+        # stream ordering against the graph segments and the byte all-gather run on a box with one GPU (tests/test_distributed_gpu.py)
+        force = os.environ.get("KP1_DIST_FORCE_SINGLE", "0") == "1"
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
         self.world_size = dist.get_world_size() if self.enabled else 1
         self.rank = dist.get_rank() if self.enabled else 0
         self.backend = str(dist.get_backend()) if self.enabled else ""

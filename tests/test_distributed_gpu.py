@@ -99,13 +99,19 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         dist.destroy_process_group()
 
 
-def _segmented_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+def _segmented_worker(rank: int, world: int, port: int, out_dir: str, backend: str = "gloo", mode: str = "segmented") -> None:
     """the same two-iteration training run twice in one process: hipGraph segments with eager collectives between them, then every launch
-    eager.  Both must leave bit-identical parameters, Adam moments, rollout buffers and curriculum tracker state on every rank."""
+    eager.  Both must leave bit-identical parameters, Adam moments, rollout buffers and curriculum tracker state on every rank.
+    backend "nccl" with world 1 (KP1_DIST_FORCE_SINGLE): the same run with the collectives going through RCCL on its own stream."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        os.environ["KP1_DIST_FORCE_SINGLE"] = "1"
+        os.environ["KP1_DIST_GRAPHS"] = "1" if mode == "captured" else "0"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from conftest import load_golden_config
         from rl_brain_trainer_amd import ppo as P
@@ -127,24 +133,38 @@ def _segmented_worker(rank: int, world: int, port: int, out_dir: str) -> None:
             st = cur.read()
             out = (ppo.policy.flat.clone(), ppo.adam_m.clone(), ppo.adam_v.clone(), ppo.adv_buf.clone(), ppo.obs_buf.clone(),
                    (st.stage_index, st.stage_episode_count, st.ring_len, st.ring_head, st.n_events, st.num_timesteps), ppo.graph_mode,
-                   None if not use_graphs else (ppo._rollout_graph.n_graphs, ppo._epoch_graph.n_graphs))
+                   None if not use_graphs else (getattr(ppo._rollout_graph, "n_graphs", 1), getattr(ppo._epoch_graph, "n_graphs", 1)))
             cur.close()
             env.close()
             return out
 
         seg, eager = run(True), run(False)
-        assert seg[6] == "segmented" and eager[6] == "none"
+        assert seg[6] == mode and eager[6] == "none", seg[6]
         # rollout: one segment per done-exchange chunk + the tail; epoch: advantage sums | stats + first tile ... | last Adam
-        assert seg[7][0] == T // 16 + 1 and seg[7][1] == (T * N) // 1024 + 2, seg[7]
+        if mode == "segmented":
+            assert seg[7][0] == T // 16 + 1 and seg[7][1] == (T * N) // 1024 + 2, seg[7]
         for a, b in zip(seg[:5], eager[:5]):
             assert torch.equal(a, b)
         assert seg[5] == eager[5] and seg[5][0] > 2 and seg[5][5] == 3 * T * N * world       # the tracker promoted, on global timesteps
         both = [None] * world
         dist.all_gather_object(both, seg[0].cpu().numpy())
-        assert np.array_equal(both[0], both[1])
+        assert all(np.array_equal(both[0], b) for b in both)
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
+
+
+def test_one_rank_rccl_segmented_graphs_match_eager(tmp_path):
+    """the data-parallel path over the REAL backend (RCCL: all-reduce and byte all-gather on RCCL's stream, ordered against the graph segments
+    of the launch stream), as far as one GPU can show it: a one-rank group that takes the multi-rank code path"""
+    mp.spawn(_segmented_worker, args=(1, _free_port(), str(tmp_path), "nccl"), nprocs=1, join=True)
+    assert (tmp_path / "ok0").exists()
+
+
+def test_one_rank_rccl_captured_graphs_match_eager(tmp_path):
+    """the opt-in mode (KP1_DIST_GRAPHS=1): RCCL collectives captured INSIDE the rollout and epoch graphs, one rank"""
+    mp.spawn(_segmented_worker, args=(1, _free_port(), str(tmp_path), "nccl", "captured"), nprocs=1, join=True)
+    assert (tmp_path / "ok0").exists()
 
 
 def test_two_rank_segmented_graphs_match_eager(tmp_path):
