@@ -229,6 +229,36 @@ class Dist:
         self.backend = str(dist.get_backend()) if self.enabled else ""
         self._graphs_ok: bool | None = None
         self._segments: GraphSegments | None = None     # set while a segmented capture records: collectives become cut points
+        self.rccl = None                                # rccl.RcclComm once use_stream_collectives() has agreed on it
+        self.collectives = "torch.distributed" if self.enabled else "none"
+
+    def use_stream_collectives(self, device: torch.device) -> bool:
+        """nccl backend: put the training collectives on the LAUNCH stream (rccl.RcclComm: same RCCL, no hop to torch's NCCL stream and back per
+        call).  Collective: call on every rank.  Every rank self-tests its communicator and the verdicts are combined through torch.distributed,
+        so all ranks take the same path; any failure (library, bootstrap, a wrong sum) leaves the torch.distributed path in place.
+        KP1_RCCL_DIRECT=0 switches it off."""
+        if not self.enabled or self.backend != "nccl" or self.rccl is not None or os.environ.get("KP1_RCCL_DIRECT", "1") == "0":
+            return self.rccl is not None
+        import sys
+
+        dog = self.watchdog(180.0, "the RCCL communicator bootstrap (KP1_RCCL_DIRECT=0 keeps the collectives on torch.distributed)")
+        comm, ok = None, False
+        try:
+            from . import rccl
+
+            comm = rccl.RcclComm(self.dist, device)
+            ok = comm.self_test()
+        except Exception as exc:  # noqa: BLE001 -- whatever goes wrong here, the torch.distributed path is complete by itself
+            print(f"[kp1] rank {self.rank}: RCCL on the launch stream not available ({type(exc).__name__}: {exc}); collectives stay on torch.distributed", flush=True, file=sys.stderr)
+        verdict = torch.tensor([1.0 if ok else 0.0], device=device)
+        self.dist.all_reduce(verdict, op=self.dist.ReduceOp.MIN)
+        dog.cancel()
+        if verdict.item() > 0.5:
+            self.rccl = comm
+            self.collectives = "rccl on the launch stream"
+        elif comm is not None:
+            comm.close()
+        return self.rccl is not None
 
     def _collective(self, fn) -> None:
         if self._segments is not None:
@@ -238,7 +268,10 @@ class Dist:
 
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         if self.enabled:
-            self._collective(lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM))
+            if self.rccl is not None and t.is_cuda and t.is_contiguous():
+                self._collective(lambda: self.rccl.all_reduce_sum(t))
+            else:
+                self._collective(lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM))
         return t
 
     def all_gather_bytes(self, t: torch.Tensor) -> torch.Tensor:
@@ -252,7 +285,10 @@ class Dist:
         """out[world, ...] <- every rank's t (rank-major), into a caller-owned buffer (graph replays need a fixed address)."""
         if self.enabled:
             dst, src = out.view(-1), t.contiguous().view(-1)
-            self._collective(lambda: self.dist.all_gather_into_tensor(dst, src))
+            if self.rccl is not None and src.is_cuda:
+                self._collective(lambda: self.rccl.all_gather(dst, src))
+            else:
+                self._collective(lambda: self.dist.all_gather_into_tensor(dst, src))
         else:
             out.view(-1).copy_(t.reshape(-1))
         return out
@@ -281,7 +317,7 @@ class Dist:
         import threading
 
         def _hung() -> None:
-            print(f"[kp1] {what} did not complete within {seconds:.0f} s: re-run with KP1_DIST_GRAPHS=0 (segmented graphs, eager collectives)",
+            print(f"[kp1] {what} did not complete within {seconds:.0f} s: re-run with KP1_DIST_GRAPHS=0 KP1_RCCL_DIRECT=0 (segmented graphs, torch.distributed collectives)",
                   file=sys.stderr, flush=True)
             os._exit(3)
 
@@ -415,6 +451,8 @@ class PPO:
         # hipGraph replay of the rollout (T x 3 launches) and of one update epoch.  Data parallel: graph segments with eager collectives
         # between them, or (opt-in) the RCCL collectives captured inside the graphs: Dist.graph_mode.
         self.use_graphs = bool(use_graphs and backend == "hip")
+        if backend == "hip":
+            self.dist.use_stream_collectives(self.device)     # nccl: the training collectives go on the launch stream (rccl.py); else a no-op
         self.graph_mode = self.dist.graph_mode(self.device) if self.use_graphs else "none"
         self._first_replay_checked = {"rollout": not (self.dist.enabled and self.graph_mode == "captured"),
                                       "epoch": not (self.dist.enabled and self.graph_mode == "captured")}

@@ -99,7 +99,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         dist.destroy_process_group()
 
 
-def _segmented_worker(rank: int, world: int, port: int, out_dir: str, backend: str = "gloo", mode: str = "segmented") -> None:
+def _segmented_worker(rank: int, world: int, port: int, out_dir: str, backend: str = "gloo", mode: str = "segmented", direct: bool = True) -> None:
     """the same two-iteration training run twice in one process: hipGraph segments with eager collectives between them, then every launch
     eager.  Both must leave bit-identical parameters, Adam moments, rollout buffers and curriculum tracker state on every rank.
     backend "nccl" with world 1 (KP1_DIST_FORCE_SINGLE): the same run with the collectives going through RCCL on its own stream."""
@@ -109,6 +109,7 @@ def _segmented_worker(rank: int, world: int, port: int, out_dir: str, backend: s
     if backend == "nccl":
         os.environ["KP1_DIST_FORCE_SINGLE"] = "1"
         os.environ["KP1_DIST_GRAPHS"] = "1" if mode == "captured" else "0"
+        os.environ["KP1_RCCL_DIRECT"] = "1" if direct else "0"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -131,6 +132,7 @@ def _segmented_worker(rank: int, world: int, port: int, out_dir: str, backend: s
                 ppo.train()
             torch.cuda.synchronize()
             st = cur.read()
+            assert ppo.dist.collectives == ("rccl on the launch stream" if backend == "nccl" and direct else "torch.distributed")
             out = (ppo.policy.flat.clone(), ppo.adam_m.clone(), ppo.adam_v.clone(), ppo.adv_buf.clone(), ppo.obs_buf.clone(),
                    (st.stage_index, st.stage_episode_count, st.ring_len, st.ring_head, st.n_events, st.num_timesteps), ppo.graph_mode,
                    None if not use_graphs else (getattr(ppo._rollout_graph, "n_graphs", 1), getattr(ppo._epoch_graph, "n_graphs", 1)))
@@ -154,16 +156,19 @@ def _segmented_worker(rank: int, world: int, port: int, out_dir: str, backend: s
         dist.destroy_process_group()
 
 
-def test_one_rank_rccl_segmented_graphs_match_eager(tmp_path):
-    """the data-parallel path over the REAL backend (RCCL: all-reduce and byte all-gather on RCCL's stream, ordered against the graph segments
-    of the launch stream), as far as one GPU can show it: a one-rank group that takes the multi-rank code path"""
-    mp.spawn(_segmented_worker, args=(1, _free_port(), str(tmp_path), "nccl"), nprocs=1, join=True)
+@pytest.mark.parametrize("direct", [True, False])
+def test_one_rank_rccl_segmented_graphs_match_eager(tmp_path, direct):
+    """the data-parallel path over the REAL backend, as far as one GPU can show it: a one-rank RCCL group that takes the multi-rank code path.
+    direct: the all-reduces and byte all-gathers are enqueued on the launch stream itself (rccl.RcclComm, the default with nccl), between the
+    graph segments; otherwise through torch.distributed, on its NCCL stream."""
+    mp.spawn(_segmented_worker, args=(1, _free_port(), str(tmp_path), "nccl", "segmented", direct), nprocs=1, join=True)
     assert (tmp_path / "ok0").exists()
 
 
-def test_one_rank_rccl_captured_graphs_match_eager(tmp_path):
+@pytest.mark.parametrize("direct", [True, False])
+def test_one_rank_rccl_captured_graphs_match_eager(tmp_path, direct):
     """the opt-in mode (KP1_DIST_GRAPHS=1): RCCL collectives captured INSIDE the rollout and epoch graphs, one rank"""
-    mp.spawn(_segmented_worker, args=(1, _free_port(), str(tmp_path), "nccl", "captured"), nprocs=1, join=True)
+    mp.spawn(_segmented_worker, args=(1, _free_port(), str(tmp_path), "nccl", "captured", direct), nprocs=1, join=True)
     assert (tmp_path / "ok0").exists()
 
 
