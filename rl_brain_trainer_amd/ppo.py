@@ -458,6 +458,9 @@ class PPO:
                                       "epoch": not (self.dist.enabled and self.graph_mode == "captured")}
         self._rollout_graph = None
         self._epoch_graph = None
+        self._epoch_policy = os.environ.get("KP1_DP_EPOCH", "auto")     # segmented mode only: "auto" (measured), "graph", "eager"
+        self._epoch_auto = None
+        self.epoch_form = "one graph" if self.graph_mode == "captured" else ("eager launches" if self.graph_mode == "none" or self._epoch_policy == "eager" else "graph segments")
         self._rollout_graph_key = None     # (env.launch_args_version, curriculum attached?) the rollout graph was captured with
         self._epoch_graph_key = None       # hyper-parameters baked into the epoch graph's kernel arguments
         self._kernels_warm = False         # the rollout kernels have run once (code objects loaded, attributes set)
@@ -843,7 +846,20 @@ class PPO:
                         continue
                     self._capture_epoch(obs, act, old_logp, adv, ret, total, local_bs)
                     self._epoch_graph_key = self._epoch_key()
-                self._replay_checked("epoch", self._epoch_graph)
+                    self._epoch_auto = {"phase": 0} if (self.graph_mode == "segmented" and self._epoch_policy == "auto") else None
+                    self._replay_checked("epoch", self._epoch_graph)      # the first replay carries one-time costs: never the timed one
+                    n_updates += (total + local_bs - 1) // local_bs
+                    self.adam_t += (total + local_bs - 1) // local_bs
+                    continue
+                if self.graph_mode == "segmented" and self._segmented_epoch_eager():
+                    # data parallel, segments measured slower than eager launches on this box (same bits either way)
+                    mb_stats = self._epoch_adv_stats(adv, self.perm, total, local_bs)
+                    for i, start in enumerate(range(0, total, local_bs)):
+                        self._hip_minibatch_step(obs, self.perm[start:start + local_bs], act, old_logp, adv, ret, device_step=True,
+                                                 adv_stats=None if mb_stats is None else mb_stats[i])
+                else:
+                    self._replay_checked("epoch", self._epoch_graph)
+                self._segmented_epoch_timed()
                 n_updates += (total + local_bs - 1) // local_bs
                 self.adam_t += (total + local_bs - 1) // local_bs
                 continue
@@ -867,6 +883,40 @@ class PPO:
         # read back lazily (last_stats): a .tolist() here would make every iteration wait for its own update before the host can enqueue
         # the next rollout
         self._last_stats_dev = (stats, n_updates)
+
+    # Data parallel, graph_mode "segmented": an update epoch is 64 graph segments of four kernels with a collective between them.  A hipGraph
+    # launch boundary costs more on the GPU timeline than a kernel boundary of an eager launch (one-rank RCCL group on one MI355X, collectives
+    # stubbed out: 48.9 ms per update as segments, 45.6 ms as eager launches, 43.7 ms as ONE graph without a process group), while a slow or
+    # busy host favours the segments.  Both forms leave the same bits (tests/test_distributed_gpu.py), so the choice is measured: after the
+    # capture, one replayed epoch and one eager epoch are timed with events, the times are max-reduced over the ranks, and the faster form
+    # runs from then on (KP1_DP_EPOCH=graph|eager pins it).
+    def _segmented_epoch_eager(self) -> bool:
+        if self._epoch_policy != "auto":
+            return self._epoch_policy == "eager"
+        a = self._epoch_auto
+        if a is None:
+            return False
+        if a["phase"] in (0, 1):          # phase 0: time a replay; phase 1: time an eager epoch
+            a["ev"] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            a["ev"][0].record()
+            return a["phase"] == 1
+        return bool(a["eager"])
+
+    def _segmented_epoch_timed(self) -> None:
+        a = self._epoch_auto
+        if a is None or self._epoch_policy != "auto" or a["phase"] > 1:
+            return
+        a["ev"][1].record()
+        a["t_graph" if a["phase"] == 0 else "t_eager"] = a["ev"]
+        a["phase"] += 1
+        if a["phase"] == 2:
+            torch.cuda.synchronize(self.device)
+            t = torch.tensor([a["t_graph"][0].elapsed_time(a["t_graph"][1]), a["t_eager"][0].elapsed_time(a["t_eager"][1])], dtype=torch.float64, device=self.device)
+            if self.dist.enabled:
+                self.dist.dist.all_reduce(t, op=self.dist.dist.ReduceOp.MAX)      # every rank takes the same form
+            a["ms"] = [float(x) for x in t.tolist()]
+            a["eager"] = a["ms"][1] < a["ms"][0]
+            self.epoch_form = "eager launches" if a["eager"] else "graph segments"
 
     @property
     def last_stats(self) -> dict[str, float]:
