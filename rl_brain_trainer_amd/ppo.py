@@ -260,6 +260,13 @@ class Dist:
             comm.close()
         return self.rccl is not None
 
+    def close(self) -> None:
+        """destroy the launch-stream RCCL communicator (collective in effect: call on every rank, after the last training collective has completed)"""
+        if self.rccl is not None:
+            self.rccl.close()
+            self.rccl = None
+            self.collectives = "torch.distributed" if self.enabled else "none"
+
     def _collective(self, fn) -> None:
         if self._segments is not None:
             self._segments.cut(fn)

@@ -130,6 +130,7 @@ def main(argv: list[str] | None = None) -> dict[str, Any]:
         import torch.distributed as dist
 
         dist.barrier()
+        ppo.dist.close()
         dist.destroy_process_group()
     return summary
 
