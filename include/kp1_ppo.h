@@ -233,6 +233,12 @@ int kp1_mlp_adam_step(kp1_mlp* m, float* params, float* grad, float* exp_avg, fl
  *   out_ms[4] mlp_tile_kernel<true> (hidden 256: layer 1 + layer 2 + heads + loss + activation backward of both nets)
  *   out_ms[5] gemm_tn_frag_kernel (hidden 256: dW2 + dW1 of both nets)          [4], [5] = 0 for other widths
  * out_flops[k] = algorithmic FLOPs of one launch of kernel k (2*M*N*K summed over its GEMMs and both nets). */
+/* Placement self-check of the two SPEED assumptions of the update kernels (never correctness): launches a probe with the training tile's launch
+ * shape for an n_rows minibatch and reports where the hardware put the workgroups.  out[8] (host): [0] workgroups, [1] pairs (k, k + #CUs) probed,
+ * [2] of them on the same CU (what the tile kernel's 12 us stagger assumes), [3] workgroups that run on the XCD of workgroup (linear index % 8)
+ * and [7] distinct XCDs among workgroups 0..7 (what the weight-gradient kernel's chunk-major block order assumes: [3] = all, [7] = 8),
+ * [4] #CUs, [5] distinct CUs used, [6] workgroups that arrived while the probe waited. */
+int kp1_mlp_placement_check(int32_t device, int32_t n_rows, int32_t* out, void* stream);
 int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32_t n, int32_t iters, float* out_ms, double* out_flops,
                          void* stream);
 

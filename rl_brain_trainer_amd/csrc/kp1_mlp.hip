@@ -1919,6 +1919,73 @@ int kp1_mlp_time_kernels(kp1_mlp* m, const float* obs, int32_t obs_stride, int32
   return KP1_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- placement self-check
+// Two SPEED assumptions of the update kernels rest on how the hardware places workgroups (never correctness): the training tile holds back
+// the workgroups with linear index in [#CUs, 2 #CUs) on the assumption that workgroup k + #CUs lands on the CU of workgroup k (the second tile
+// of a CU), and the weight-gradient kernel makes the batch chunk the fast block index on the assumption that block b runs on XCD b % 8.  This
+// probe launches a kernel with the training tile's launch shape (grid, block, dynamic LDS, two workgroups per CU), keeps every workgroup resident
+// until all have arrived (bounded wait), and records where each one ran.
+__global__ void __launch_bounds__(FuGeom<true>::NTH, FuGeom<true>::WG_PER_CU * FuGeom<true>::NTH / 256) placement_probe_kernel(unsigned int* __restrict__ where, unsigned int* __restrict__ arrived,
+                                                                                                                            unsigned int total) {
+  extern __shared__ float lds[];
+  if (threadIdx.x == 0) {
+    const unsigned int hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID: wave, SIMD, pipe, CU, SH, SE
+    const unsigned int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);     // HW_REG_XCC_ID[3:0]
+    const unsigned int linear = blockIdx.x + gridDim.x * blockIdx.z;
+    where[linear] = (xcc << 16) | (((hw >> 13) & 7u) << 8) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);   // XCD | SE | SH | CU
+    lds[0] = 0.f;
+    __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total && wall_clock64() - t0 < 200000ull) __builtin_amdgcn_s_sleep(8);   // <= 2 ms
+  }
+  __syncthreads();
+}
+
+int kp1_mlp_placement_check(int32_t device, int32_t n_rows, int32_t* out, void* stream_) {
+  // out[0] workgroups, out[1] pairs (k, k + #CUs) probed, out[2] pairs on the same CU, out[3] workgroups on the XCD of workgroup (index % 8),
+  // out[4] #CUs, out[5] distinct CUs used, out[6] workgroups that arrived while the probe waited, out[7] distinct XCDs among workgroups 0..7
+  if (!out || n_rows <= 0) return fail(KP1_ERR_INVALID, "bad argument to kp1_mlp_placement_check");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t stream = (hipStream_t)stream_;
+  using G = FuGeom<true>;
+  int n_cus = 0;
+  HIP_TRY(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, device));
+  const dim3 grid((n_rows + G::BM - 1) / G::BM, 1, 2);
+  const unsigned int total = grid.x * grid.z;
+  if ((int)total > G::WG_PER_CU * n_cus) return fail(KP1_ERR_UNSUPPORTED, "placement probe: the grid must be resident at once");
+  unsigned int* dev = nullptr;
+  HIP_TRY(hipMalloc(&dev, sizeof(unsigned int) * (total + 1)));
+  HIP_TRY(hipMemsetAsync(dev, 0, sizeof(unsigned int) * (total + 1), stream));
+  const size_t bytes = sizeof(float) * G::LDS_FLOATS;
+  HIP_TRY(hipFuncSetAttribute((const void*)placement_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  hipLaunchKernelGGL(placement_probe_kernel, grid, dim3(G::NTH), bytes, stream, dev, dev + total, total);
+  std::vector<unsigned int> host(total + 1);
+  hipError_t e = hipMemcpyAsync(host.data(), dev, sizeof(unsigned int) * (total + 1), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(dev);
+  HIP_TRY(e);
+  int pairs = 0, same = 0, rr = 0;
+  std::vector<unsigned int> seen;
+  for (unsigned int k = 0; k < total; ++k) {
+    if ((host[k] >> 16) == (host[k & 7u] >> 16)) ++rr;      // same XCD as the first workgroup of its residue class (the XCD numbering itself is the hardware's)
+    if (k + (unsigned)n_cus < total) {
+      ++pairs;
+      if (host[k] == host[k + n_cus]) ++same;
+    }
+    bool fresh = true;
+    for (unsigned int v : seen) fresh = fresh && v != host[k];
+    if (fresh) seen.push_back(host[k]);
+  }
+  int xcds = 0;
+  for (unsigned int a = 0; a < 8 && a < total; ++a) {
+    bool fresh = true;
+    for (unsigned int b = 0; b < a; ++b) fresh = fresh && (host[a] >> 16) != (host[b] >> 16);
+    xcds += fresh ? 1 : 0;
+  }
+  out[0] = (int)total; out[1] = pairs; out[2] = same; out[3] = rr; out[4] = n_cus; out[5] = (int)seen.size(); out[6] = (int)host[total]; out[7] = xcds;
+  return KP1_OK;
+}
+
 #ifdef KP1_CLK_TRACE
 int kp1_debug_clk_trace(unsigned long long* out) {
   HIP_TRY(hipDeviceSynchronize());

@@ -29,6 +29,7 @@ class MlpKernels:
         L.kp1_mlp_loss_grad.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, f32, f32, vp, f32, f32, f32, f32, vp, vp, i32, vp]
         L.kp1_mlp_adam_step.argtypes = [vp, vp, vp, vp, vp, f32, f32, f32, i32, i32, vp]
         L.kp1_mlp_time_kernels.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+        L.kp1_mlp_placement_check.argtypes = [i32, i32, vp, vp]
         L.kp1_mlp_set_option.argtypes = [vp, i32, i32]
         L.kp1_mlp_profile_read.argtypes = [vp, vp, vp]
         self.hidden = hidden
@@ -127,6 +128,15 @@ class MlpKernels:
         partials its finalize kernel left are reused and the separate norm reduction launch is skipped."""
         native.check(self.L.kp1_mlp_adam_step(self._h, _p(params), _p(grad), _p(exp_avg), _p(exp_avg_sq), lr, eps, max_grad_norm, step,
                                               2 if fused_norm else 0, self._stream()))
+
+    def placement_check(self, n_rows: int) -> dict[str, int | float]:
+        """where the hardware puts the workgroups of a training-tile launch for an n_rows minibatch (the two placement assumptions the update
+        kernels' SPEED rests on: include/kp1_ppo.h kp1_mlp_placement_check)"""
+        out = (C.c_int32 * 8)()
+        native.check(self.L.kp1_mlp_placement_check(self.device.index or 0, int(n_rows), C.cast(out, C.c_void_p), self._stream()))
+        wgs, pairs, same, rr, cus, used, arrived, xcds = (int(v) for v in out)
+        return {"workgroups": wgs, "compute_units": cus, "compute_units_used": used, "second_tile_on_same_cu": same, "second_tile_pairs": pairs,
+                "on_xcd_of_block_index_mod_8": rr, "xcds_among_first_8_blocks": xcds, "all_resident": arrived == wgs}
 
     def time_kernels(self, obs: torch.Tensor, n: int, iters: int = 20) -> dict[str, dict[str, float]]:
         """HIP-event timings of the MFMA GEMM kernels at minibatch size n (bench.py roofline block)."""

@@ -298,6 +298,23 @@ def test_device_curriculum_parallel_path_equals_serial_replay(window, min_eps, m
     small.close()
 
 
+def test_placement_self_check_reports_the_launch_shape():
+    """kp1_mlp_placement_check: the probe has the training tile's launch shape (two workgroups of 8192 / 32 tiles x 2 nets per CU), every workgroup
+    is resident at once, and the report is internally consistent.  What the placement IS on the box is reported by bench.py, not asserted here: the
+    assumptions are speed assumptions."""
+    from rl_brain_trainer_amd.mlp import MlpKernels
+
+    mlp = MlpKernels(256, torch.device(DEV), max_batch=8192)
+    rep = mlp.placement_check(8192)
+    assert rep["workgroups"] == 512 and rep["all_resident"]
+    assert 0 < rep["compute_units_used"] <= rep["compute_units"]
+    assert rep["second_tile_pairs"] == 512 - rep["compute_units"] and 0 <= rep["second_tile_on_same_cu"] <= rep["second_tile_pairs"]
+    assert 0 <= rep["on_xcd_of_block_index_mod_8"] <= 512 and 1 <= rep["xcds_among_first_8_blocks"] <= 8
+    small = mlp.placement_check(512)
+    assert small["workgroups"] == 32 and small["second_tile_pairs"] == 0
+    mlp.close()
+
+
 def test_keyed_permutation_is_a_permutation_and_mixes():
     """kp1_random_permutation (the minibatch shuffle above 2^17 samples): a bijection of [0, n) for any n (cycle walking below the next
     power of two), different keys give different permutations, and consecutive outputs -- one minibatch is a run of them -- look like
