@@ -1332,7 +1332,7 @@ int launch_tn(kp1_mlp* m, GemmTN t, int n_o_tiles, int slab_cols, float* slab, i
 int launch_fused(const FusedArgs& fa_in, hipStream_t stream) {
   using G = FuGeom<true>;
   FusedArgs fa = fa_in;
-  static const int stagger_us = [] { const char* e = std::getenv("KP1_FU_STAGGER_US"); return e ? std::atoi(e) : 12; }();  // tuning knob
+  static const int stagger_us = [] { const char* e = std::getenv("KP1_FU_STAGGER_US"); return e ? std::atoi(e) : 11; }();  // tuning knob; re-swept in round 3 (profiles/r03_ab_tile_stagger.log): 10-13 us within 0.4 us of each other, a cliff at 14 (+6 us)
   static const int n_cus = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
