@@ -90,6 +90,9 @@ __device__ unsigned long long kp1_clk_buf[2 * 1024 * 4];   // [kernel: 0 tile, 1
 #ifndef KP1_TNF_LD_NT
 #define KP1_TNF_LD_NT 0    // weight-gradient kernel: activation operand loads non-temporal
 #endif
+#ifndef KP1_TNS_LD_AUX
+#define KP1_TNS_LD_AUX 16  // wave-split weight-gradient kernel: the activation-fragment loads bypass the CU's L1 (sc1; no reuse inside a CU): 25.4 -> 24.4 us in situ, nt 26.5 (profiles/r03_ab_tn_load_policy.log)
+#endif
 #ifndef KP1_FIN_LD_NT
 #define KP1_FIN_LD_NT 0    // finalize kernel: partial-slab loads non-temporal
 #endif
@@ -105,6 +108,16 @@ __device__ __forceinline__ void store16(float* __restrict__ base, int64_t idx, c
   } else {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)(idx * 4), 0, AUX);
+  }
+}
+// 16-byte load at base[off] (floats) with cache-policy bits (raw buffer load: 1 sc0, 2 nt, 16 sc1); AUX = 0: a plain global load
+template <int AUX>
+__device__ __forceinline__ f32x4 load16_aux(const float* __restrict__ base, int64_t off) {
+  if constexpr (AUX == 0) {
+    return *reinterpret_cast<const f32x4*>(base + off);
+  } else {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off * 4), 0, AUX));
   }
 }
 template <int NT>
