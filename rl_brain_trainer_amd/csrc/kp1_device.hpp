@@ -254,6 +254,30 @@ struct EnvState {
 #endif
   }
   __device__ __forceinline__ R& r(int f, int64_t i) const { return at<R>(real, f, n, i); }
+#ifndef KP1_ENV_LD_AUX
+#define KP1_ENV_LD_AUX 16  // cache-policy bits of the step's state loads (fp32 handle; 0 = plain loads): sc1, not allocated in the CU's L1: 7.9 -> 7.7 us at 4096 envs, 10.09 -> 9.89 us at 32768 (profiles/r03_ab_env_load_policy.log)
+#endif
+  // state loads of the step path: every field is read once per step, nothing is reused through the CU's L1
+  __device__ __forceinline__ R rl(int f, int64_t i) const {
+    if constexpr (KP1_ENV_LD_AUX == 0 || sizeof(R) != 4) {
+      return at<R>(real, f, n, i);
+    } else {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(real, 0, 0x7fffffff, 0x00020000);
+      return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(((uint32_t)f * (uint32_t)n + (uint32_t)i) * 4u), 0, KP1_ENV_LD_AUX));
+    }
+  }
+  __device__ __forceinline__ int32_t ivl(int f, int64_t i) const {
+    if constexpr (KP1_ENV_LD_AUX == 0) {
+      return at<int32_t>(ints, f, n, i);
+    } else {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ints, 0, 0x7fffffff, 0x00020000);
+      return __builtin_bit_cast(int32_t, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(((uint32_t)f * (uint32_t)n + (uint32_t)i) * 4u), 0, KP1_ENV_LD_AUX));
+    }
+  }
+  __device__ __forceinline__ double q_loadl(int k, int64_t i) const {
+    if constexpr (sizeof(R) == 4) return (double)rl(F_Q + k, i) + (double)rl(F_QLO + k, i);
+    else return (double)r(F_Q + k, i);
+  }
   __device__ __forceinline__ int32_t& iv(int f, int64_t i) const { return at<int32_t>(ints, f, n, i); }
   // joint position as the kinematic chain carries it (fp64).  fp32 handle: a two-float value, 48 significant bits.
   __device__ __forceinline__ double q_load(int k, int64_t i) const {
