@@ -509,16 +509,19 @@ def _run_pairs_columns(*, pairs, starts_by_id, targets_by_id, approach_policy, a
     if E == 0:
         return torch.zeros((0, len(_COLS)), dtype=torch.float64, device=dev)
     nj = kcfg.NJ
-    starts = [starts_by_id[p["start_id"]] for p in pairs]
-    targets = [targets_by_id[p["target_id"]] for p in pairs]
-    opts = {
-        "initial_q": np.array([s["q_start"] for s in starts], dtype=float),
-        "initial_dq": np.array([s.get("dq_start", [0.0] * nj) for s in starts], dtype=float),
-        "initial_prev_action": np.array([s.get("prev_action", [0.0] * nj) for s in starts], dtype=float),
-        "goal_q": np.array([t["q_target"] for t in targets], dtype=float),
-        "goal_pose6": np.array([[*t["ee_target_position"], *t["ee_target_orientation"]] for t in targets], dtype=float),
-        "policy_mode": "approach",
-    }
+    # the maps are a few hundred rows, the pair list tens of thousands: one table per map, one index vector per pair list
+    s_ids, t_ids = list(starts_by_id), list(targets_by_id)
+    s_row, t_row = {k: i for i, k in enumerate(s_ids)}, {k: i for i, k in enumerate(t_ids)}
+    S = [starts_by_id[k] for k in s_ids]
+    T = [targets_by_id[k] for k in t_ids]
+    s_q = np.array([s["q_start"] for s in S], dtype=float).reshape(len(S), nj)
+    s_dq = np.array([s.get("dq_start", [0.0] * nj) for s in S], dtype=float).reshape(len(S), nj)
+    s_pa = np.array([s.get("prev_action", [0.0] * nj) for s in S], dtype=float).reshape(len(S), nj)
+    t_q = np.array([t["q_target"] for t in T], dtype=float).reshape(len(T), nj)
+    t_pose = np.array([[*t["ee_target_position"], *t["ee_target_orientation"]] for t in T], dtype=float).reshape(len(T), 6)
+    si = np.fromiter((s_row[p["start_id"]] for p in pairs), dtype=np.int64, count=E)
+    ti = np.fromiter((t_row[p["target_id"]] for p in pairs), dtype=np.int64, count=E)
+    opts = {"initial_q": s_q[si], "initial_dq": s_dq[si], "initial_prev_action": s_pa[si], "goal_q": t_q[ti], "goal_pose6": t_pose[ti], "policy_mode": "approach"}
     r = approach_cfg.c.reward
     env = ArmKinematicVecEnv(approach_cfg, E, device=device, seed=seed, first_env_id=first_env_id)
     if obs_stride != 56:
