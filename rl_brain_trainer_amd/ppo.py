@@ -240,23 +240,35 @@ class Dist:
         if not self.enabled or self.backend != "nccl" or self.rccl is not None or os.environ.get("KP1_RCCL_DIRECT", "1") == "0":
             return self.rccl is not None
         import sys
+        import threading
 
-        dog = self.watchdog(180.0, "the RCCL communicator bootstrap (KP1_RCCL_DIRECT=0 keeps the collectives on torch.distributed)")
-        comm, ok = None, False
-        try:
-            from . import rccl
+        # The bootstrap runs in a helper thread with a deadline: a rank whose ncclCommInitRank does not return (a peer that never arrives) reports
+        # "not available" like any other failure and every rank stays on torch.distributed -- a slow path instead of a dead run.
+        box: dict[str, Any] = {}
 
-            comm = rccl.RcclComm(self.dist, device)
-            ok = comm.self_test()
-        except Exception as exc:  # noqa: BLE001 -- whatever goes wrong here, the torch.distributed path is complete by itself
-            print(f"[kp1] rank {self.rank}: RCCL on the launch stream not available ({type(exc).__name__}: {exc}); collectives stay on torch.distributed", flush=True, file=sys.stderr)
+        def boot() -> None:
+            try:
+                from . import rccl
+
+                torch.cuda.set_device(device)          # the current device is per thread
+                box["comm"] = rccl.RcclComm(self.dist, device)
+                box["ok"] = box["comm"].self_test()
+            except Exception as exc:  # noqa: BLE001 -- whatever goes wrong here, the torch.distributed path is complete by itself
+                box["exc"] = exc
+
+        worker = threading.Thread(target=boot, name="kp1-rccl-bootstrap", daemon=True)
+        worker.start()
+        worker.join(float(os.environ.get("KP1_RCCL_BOOT_SECONDS", "120")))
+        comm, ok = box.get("comm"), bool(box.get("ok")) and not worker.is_alive()
+        if not ok:
+            why = "no answer within the deadline" if worker.is_alive() else (f"{type(box['exc']).__name__}: {box['exc']}" if "exc" in box else "self-test mismatch")
+            print(f"[kp1] rank {self.rank}: RCCL on the launch stream not available ({why}); collectives stay on torch.distributed", flush=True, file=sys.stderr)
         verdict = torch.tensor([1.0 if ok else 0.0], device=device)
         self.dist.all_reduce(verdict, op=self.dist.ReduceOp.MIN)
-        dog.cancel()
         if verdict.item() > 0.5:
             self.rccl = comm
             self.collectives = "rccl on the launch stream"
-        elif comm is not None:
+        elif comm is not None and not worker.is_alive():
             comm.close()
         return self.rccl is not None
 

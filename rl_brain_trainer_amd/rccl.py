@@ -8,8 +8,9 @@ kernels go straight into the stream the tile / weight-gradient / Adam kernels ar
 replayed between graph segments or captured.
 
 The communicator is bootstrapped the way torch bootstraps its own: rank 0 draws an ncclUniqueId, torch.distributed carries the 128 bytes to
-the other ranks, every rank calls ncclCommInitRank.  `Dist` runs `self_test` on every rank and agrees (through torch.distributed) that all
-ranks passed before any training collective uses it; otherwise the torch path stays.
+the other ranks, every rank calls ncclCommInitRank.  `Dist` does this in a helper thread with a deadline, runs `self_test` on every rank and
+agrees (through torch.distributed) that all ranks passed before any training collective uses it; otherwise -- an exception, a wrong sum, no answer
+within the deadline -- the torch path stays.
 
 Reference: the reference has no collectives (one host process); SURVEY.md 8(e) states the exchange steps this carries.
 """
